@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors from the REFERENCE'S OWN sampler.
+
+Run in the build container only (needs /root/reference):
+
+    make -C oracle            # compiles /root/reference/base/Base.cpp -> oracle/_ref/Base.so
+    python tests/golden/make_golden.py
+
+What is committed is data only: three tiny knowledge graphs in OpenKE text format (made up here,
+not taken from the reference, which ships none) and, for each, the outputs of the reference's
+`sampling` / getters for a grid of settings (tests/golden/*.npz), plus SHA-256 digests of long
+sampling streams on the FB15k-237-shaped synthetic graph (tests/golden/fb_digests.json).
+Base.so keeps one dataset per process, so every (graph, workThreads, bern) cell runs in a child.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+GRID_W = [1, 2, 3, 8]
+GRID_BERN = [0, 1]
+GRID_SHAPE = [(7, 1, 0), (64, 2, 1), (64, 25, 0), (50, 3, 0)]  # (B, negRate, negRelRate)
+CALLS = 3
+
+
+def make_tiny_graphs():
+    from openkeonspark_amd.synthetic import write_openke_dir
+    rng = np.random.default_rng(20261003)
+    # kg_tiny: hub entity 0 whose (0, rel 0) group covers most entities; relation 5 never used;
+    # explicit duplicate lines
+    E, R = 30, 6
+    h = list(rng.integers(0, E, 90)); t = list(rng.integers(0, E, 90)); r = list(rng.integers(0, 5, 90))
+    for tail in range(2, 27):
+        h.append(0); t.append(tail); r.append(0)
+    for head in range(5, 20):
+        h.append(head); t.append(1); r.append(2)
+    for i in range(0, 24, 2):  # duplicates
+        h.append(h[i]); t.append(t[i]); r.append(r[i])
+    write_openke_dir(os.path.join(HERE, "kg_tiny"), E, R, np.array(h), np.array(t), np.array(r))
+    # kg_small: 1000 entities, skewed
+    from openkeonspark_amd.synthetic import generate_triples
+    hs, ts, rs = generate_triples(1000, 20, 6000, seed=7, dup_frac=0.01)
+    write_openke_dir(os.path.join(HERE, "kg_small"), 1000, 20, hs, ts, rs)
+    # kg_incr: incremental mode, the last 37 lines are the "new batch" (Reader.h:61-67, Base.cpp:101-103)
+    hi, ti, ri = generate_triples(60, 4, 260, seed=11, dup_frac=0.02)
+    write_openke_dir(os.path.join(HERE, "kg_incr"), 60, 4, hi, ti, ri, new_batch_total=37)
+
+
+def worker(kg_dir, W, bern, out_path, shapes, calls):
+    from oracle.oracle import ReferenceSampler
+    ref = ReferenceSampler(kg_dir, work_threads=W, bern=bern)
+    out = {
+        "totals": np.array([ref.entTotal, ref.relTotal, ref.trainTotal, ref.trainTotal_, ref.batchTotal], np.int64),
+        "seeds": ref.stream_states(),
+        "left_mean": ref.left_mean(), "right_mean": ref.right_mean(),
+        "by_head": ref.sorted_copy("head").astype(np.int32),
+        "by_tail": ref.sorted_copy("tail").astype(np.int32),
+        "by_rel": ref.sorted_copy("rel").astype(np.int32),
+    }
+    # the calls are consecutive on ONE rng state, in grid order
+    for si, (B, n, nr) in enumerate(shapes):
+        for c in range(calls):
+            h, t, r, y = ref.sampling(B, n, nr)
+            out["s%d_c%d" % (si, c)] = np.stack([h, t, r]).astype(np.int32)
+            out["y%d_c%d" % (si, c)] = y
+    out["final_states"] = ref.stream_states()
+    np.savez_compressed(out_path, **out)
+
+
+def digest_worker(kg_dir, W, bern, B, n, nr, calls, out_path):
+    from oracle.oracle import ReferenceSampler
+    ref = ReferenceSampler(kg_dir, work_threads=W, bern=bern)
+    hsh = hashlib.sha256()
+    first = None
+    for c in range(calls):
+        h, t, r, y = ref.sampling(B, n, nr)
+        hsh.update(h.tobytes()); hsh.update(t.tobytes()); hsh.update(r.tobytes())
+        if c == 0:
+            first = [h[:4].tolist(), t[:4].tolist(), r[:4].tolist(), h[B:B + 4].tolist(), t[B:B + 4].tolist()]
+    json.dump({"sha256": hsh.hexdigest(), "first": first,
+               "totals": [ref.entTotal, ref.relTotal, ref.trainTotal, ref.trainTotal_, ref.batchTotal],
+               "final_states": [int(x) for x in ref.stream_states()]}, open(out_path, "w"))
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--worker":
+        a = json.loads(sys.argv[2])
+        worker(a["kg"], a["W"], a["bern"], a["out"], a["shapes"], a["calls"])
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--digest":
+        a = json.loads(sys.argv[2])
+        digest_worker(a["kg"], a["W"], a["bern"], a["B"], a["n"], a["nr"], a["calls"], a["out"])
+        return
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    make_tiny_graphs()
+    for kg in ("kg_tiny", "kg_small", "kg_incr"):
+        for W in GRID_W:
+            for bern in GRID_BERN:
+                out = os.path.join(HERE, "%s_W%d_bern%d.npz" % (kg, W, bern))
+                arg = dict(kg=os.path.join(HERE, kg) + "/", W=W, bern=bern, out=out, shapes=GRID_SHAPE, calls=CALLS)
+                subprocess.check_call([sys.executable, __file__, "--worker", json.dumps(arg)],
+                                      stdout=subprocess.DEVNULL)
+                print("wrote", os.path.relpath(out, ROOT))
+    # FB15k-237-shaped synthetic graph: generated (not committed), digests committed
+    from openkeonspark_amd.synthetic import make_dataset, FB15K237
+    fb = make_dataset("/tmp/okes_fb15k237_shaped", FB15K237)
+    digests = {}
+    for name, (W, bern, B, n, nr, calls) in {
+        "cfg1_W1_uniform_B2721_n1": (1, 0, 2721, 1, 0, 100),
+        "cfg1_W8_uniform_B2721_n1": (8, 0, 2721, 1, 0, 100),
+        "cfg2_W8_bern_B2721_n25": (8, 1, 2721, 25, 0, 20),
+        "W8_bern_B4096_n2_nr1": (8, 1, 4096, 2, 1, 20),
+        "cfg2_W8_bern_B68028_n25": (8, 1, 68028, 25, 0, 2),
+    }.items():
+        tmp = "/tmp/okes_digest_%s.json" % name
+        arg = dict(kg=fb, W=W, bern=bern, B=B, n=n, nr=nr, calls=calls, out=tmp)
+        subprocess.check_call([sys.executable, __file__, "--digest", json.dumps(arg)], stdout=subprocess.DEVNULL)
+        d = json.load(open(tmp))
+        d.update(W=W, bern=bern, B=B, n=n, nr=nr, calls=calls)
+        digests[name] = d
+        print("digest", name, d["sha256"][:16])
+    json.dump(digests, open(os.path.join(HERE, "fb_digests.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
