@@ -1,0 +1,167 @@
+/*
+ * kge_mi355.h -- C ABI of libkge_mi355.so, the MI355X (gfx950) engine for the OpenKEonSpark hot path.
+ *
+ * Two groups of entry points:
+ *
+ *  (1) The hot-path subset of the reference's `Base.so` ABI, with the reference's exact unmangled
+ *      names and signatures, so that /root/reference/Config.py:30-31,160-170,347 binds to this
+ *      library unchanged (ctypes.cdll.LoadLibrary + the same calls).  INT = long (int64 on LP64),
+ *      REAL = float (base/Setting.h:3-4).  `sampling` runs the HIP sampler and copies the batch
+ *      into the caller's host buffers.
+ *
+ *  (2) `kge_*` entry points that replace what the reference does inside TensorFlow
+ *      (`sess.run([train_op, loss, global_step], feed_dict)`, distribute_training.py:282) with
+ *      device-resident operators: on-device sampling, fused gather/score/hinge/backward for
+ *      TransE/H/D/R, SGD / TF-parity Adam updates, scoring for prediction.  Plain pointers and
+ *      sizes only; device pointers are raw HIP device addresses (e.g. torch.Tensor.data_ptr()),
+ *      `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *
+ * Error convention: the reference has none (void functions, missing files only print;
+ * Reader.h:36-39).  Here every kge_* function returns 0 on success or a negative code, the
+ * Base-compatible void functions record a message, and `kge_last_error` returns the most recent
+ * message (empty string if none).  There is NO CPU fallback: device entry points fail with
+ * KGE_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef KGE_MI355_H
+#define KGE_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef INT
+#define INT long
+#endif
+#ifndef REAL
+#define REAL float
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * (1) Base.so-compatible entry points
+ * ---------------------------------------------------------------------------------------- */
+void setInPath(char *path);       /* replaces base/Setting.h:12-19  */
+void setOutPath(char *path);      /* replaces base/Setting.h:21-28  */
+void setWorkThreads(INT threads); /* replaces base/Setting.h:36-39: number of VIRTUAL sampler threads (rng streams + batch slices) */
+INT getWorkThreads(void);         /* replaces base/Setting.h:41-44  */
+void setBern(INT con);            /* replaces base/Setting.h:110-113 */
+void randReset(void);             /* replaces base/Random.h:8-13: seeds one 64-bit LCG stream per virtual thread from the (continuing) unseeded glibc rand() sequence */
+void importTrainFiles(void);      /* replaces base/Reader.h:26-179: parse, dedup, build the device-resident filter index */
+INT getEntityTotal(void);         /* replaces base/Setting.h:63-66  */
+INT getRelationTotal(void);       /* replaces base/Setting.h:68-71  */
+INT getTripleTotal(void);         /* replaces base/Setting.h:73-76  */
+INT getTrainTotal(void);          /* replaces base/Setting.h:78-81  (after dedup) */
+INT getTrainTotal_(void);         /* replaces base/Setting.h:84-87  (file count, duplicates kept) */
+INT getBatchTotal(void);          /* replaces base/Setting.h:90-93  (newBatchTotal, incremental mode) */
+INT getTestTotal(void);           /* replaces base/Setting.h:95-98  */
+INT getValidTotal(void);          /* replaces base/Setting.h:100-103 */
+/* replaces base/Base.cpp:149-172.  Caller-owned HOST buffers of length batchSize*(1+negRate+negRelRate),
+ * layout [B positives | B negatives round 0 | ... | relation negatives] (Base.cpp:109-139).
+ * Bit-identical to the reference for the same workThreads / bern / call history. */
+void sampling(INT *batch_h, INT *batch_t, INT *batch_r, REAL *batch_y, INT batchSize, INT negRate, INT negRelRate);
+
+/* ------------------------------------------------------------------------------------------
+ * (2) Engine entry points
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    KGE_OK = 0,
+    KGE_ERR_NO_DEVICE = -1,   /* no usable gfx950 device / HIP runtime error */
+    KGE_ERR_NO_DATASET = -2,  /* importTrainFiles / kge_import_train_arrays not done */
+    KGE_ERR_BAD_ARG = -3,
+    KGE_ERR_UNSUPPORTED = -4
+};
+
+enum { KGE_TRANSE = 0, KGE_TRANSH = 1, KGE_TRANSR = 2, KGE_TRANSD = 3 };
+
+/* copies the last error message (NUL terminated, truncated to n) and returns its length */
+size_t kge_last_error(char *buf, size_t n);
+void kge_clear_error(void);
+/* 1 when a HIP device is visible and usable, else 0 (never throws, never falls back) */
+int kge_device_available(void);
+const char *kge_version(void);
+
+/* Same as importTrainFiles but from arrays already in memory (h,t,r in FILE ORDER, duplicates
+ * kept; new_batch_total as batch2id.txt's first line, 0 = not incremental).  Restates
+ * Reader.h:82-177 without the text parse. */
+int kge_import_train_arrays(INT ent_total, INT rel_total, INT n, const INT *h, const INT *t, const INT *r,
+                            INT new_batch_total);
+
+/* Host-side copies of the index, for inspection and CPU tests.  `what` is one of
+ *   "tails_hr"  int32[trainTotal]  tails in (h,r,t) order         (= trainHead[].t, Reader.h:125)
+ *   "heads_tr"  int32[trainTotal]  heads in (t,r,h) order         (= trainTail[].h, Reader.h:126)
+ *   "rels_ht"   int32[trainTotal]  relations in (h,t,r) order     (= trainRel[].r,  Reader.h:127)
+ *   "pos"       int32[trainTotal_][4]  file-order triples (h,t,r,0)             (= trainList_no)
+ *   "grp"       int32[trainTotal_][4]  (hr_off,hr_len,tr_off,tr_len) per file-order triple
+ *   "ht"        int32[trainTotal_][2]  (ht_off,ht_len) per file-order triple
+ *   "left_mean" / "right_mean" float[relationTotal]               (Reader.h:160-177)
+ *   "bern_prob" float[relationTotal]  1000*right/(right+left)      (Base.cpp:117)
+ * Returns the number of BYTES the array holds (copying at most `bytes` of them), <0 on error. */
+int64_t kge_index_copy(const char *what, void *dst, int64_t bytes);
+
+/* rng stream states of the virtual threads (host view; Random.h:6) */
+int kge_get_stream_states(uint64_t *dst, INT n);
+int kge_set_stream_states(const uint64_t *src, INT n);
+
+/* On-device sampling of the slice of the batch owned by virtual threads [thread_lo, thread_hi)
+ * (Base.cpp:85-92 partitions the batch by thread id; a data-parallel rank owns a range of them).
+ * d_h/d_t/d_r: DEVICE int32 arrays of length out_stride*(1+negRate+negRelRate); the positive at
+ * global batch position p goes to index p - first_position(thread_lo), negative k to that +
+ * (k+1)*out_stride.  All workThreads rng streams advance exactly as one reference `sampling`
+ * call would advance them, whatever the owned range, so replicas stay in step.
+ * *n_local receives the number of positives written (may be NULL). */
+int kge_sampling_device(int32_t *d_h, int32_t *d_t, int32_t *d_r, INT batchSize, INT negRate, INT negRelRate,
+                        INT thread_lo, INT thread_hi, INT out_stride, INT *n_local, void *stream);
+/* number of batch positions owned by virtual threads [thread_lo, thread_hi) for this batchSize */
+INT kge_slice_positions(INT batchSize, INT thread_lo, INT thread_hi, INT *first_position);
+
+typedef struct kge_model_desc {
+    int32_t model;        /* KGE_TRANSE .. KGE_TRANSD  (distribute_training.py:62-69) */
+    int32_t negative_rel; /* Config.negative_rel; TransR reuses the positive's matrix when 0 (TransR.py:57) */
+    int64_t ent_total, rel_total;
+    int32_t ent_dim, rel_dim; /* TransE/H/D: both = hidden_size (TransD.py:37-40 ignores ent/rel_size) */
+    float margin;
+    int32_t reserved;
+} kge_model_desc;
+
+/* Parameter tables, by the reference's variable names (the checkpoint contract):
+ *   [0] ent_embeddings [E,De]  [1] rel_embeddings [R,Dr]
+ *   [2] normal_vectors [R,Dr] (TransH) | transfer_matrix [R,De*Dr] (TransR) | rel_transfer [R,Dr] (TransD)
+ *   [3] ent_transfer [E,De] (TransD)
+ * Dense row-major fp32, no padding. */
+#define KGE_MAX_TABLES 4
+int kge_table_shape(const kge_model_desc *m, int table, int64_t *rows, int64_t *cols);
+
+/* Fused gather -> score -> margin-ranking loss -> backward for one batch already on the device.
+ * Replaces the forward/backward half of sess.run(train_op) for TransE.py:26-51, TransH.py:33-69,
+ * TransD.py:46-84, TransR.py:36-75.
+ *   d_h,d_t,d_r : DEVICE int32[stride*(1+n_neg)], the Base.cpp:109-139 layout
+ *   n_pos       : positives in this (local) batch; n_neg = negative_ent + negative_rel
+ *   denom       : the reduce_mean denominator, GLOBAL batch_size*n_neg (TransE.py:51)
+ *   grads[i]    : DEVICE fp32 dense accumulators shaped like tables[i]; the summed (deduplicated)
+ *                 IndexedSlices gradient is ADDED into them (zero them first; the update ops
+ *                 re-zero them)
+ *   d_loss      : DEVICE float[1], receives sum(hinge)/denom of this local batch
+ */
+int kge_forward_backward(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES],
+                         const int32_t *d_h, const int32_t *d_t, const int32_t *d_r,
+                         INT n_pos, INT n_neg, INT stride, INT denom,
+                         float *const grads[KGE_MAX_TABLES], float *d_loss, void *stream);
+
+/* GradientDescentOptimizer on the summed gradient: p -= lr*g; g = 0   (distribute_training.py:98) */
+int kge_sgd_update(float *d_p, float *d_g, int64_t n, float lr, void *stream);
+/* TF1 AdamOptimizer._apply_sparse_shared on the summed gradient (distribute_training.py:96): every
+ * row decays and moves.  lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) computed by the caller; g = 0 after. */
+int kge_adam_update(float *d_p, float *d_m, float *d_v, float *d_g, int64_t n, float lr_t, float beta1,
+                    float beta2, float eps, void *stream);
+
+/* predict op: score n triples.  TransE: mean over the dimension (TransE.py:58); others: sum
+ * (TransH.py:82, TransR.py:87 with predict_r[0]'s matrix for all, TransD.py:98). */
+int kge_predict(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES], const int32_t *d_h,
+                const int32_t *d_t, const int32_t *d_r, INT n, float *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KGE_MI355_H */

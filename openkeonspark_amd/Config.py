@@ -1,0 +1,403 @@
+"""`Config`: the reference's binding / hyper-parameter / session object (/root/reference/Config.py)
+re-hosted on the MI355X engine.
+
+Same constructor, setters, attributes, `init()` and `sampling()` as the reference
+(Config.py:17-72,153-210,225-347), so `distribute_training.get_conf`-style callers work unchanged
+(distribute_training.py:32-71).  What the reference did with a TensorFlow session --
+`sess.run([train_op, loss, global_step], feed_dict)` (distribute_training.py:282) built by
+`create_model` (distribute_training.py:74-105) -- is `train_step()` here: sample on the device,
+run the fused forward/backward operator, exchange gradients over RCCL when data-parallel, apply
+SGD or TF-parity Adam.  Nothing in this module computes on the CPU; without the HIP library or a
+GPU the device calls raise.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import KgeError
+
+
+class Config(object):
+    '''
+    use ctypes to call the engine's C ABI from python and set essential parameters.
+    '''
+
+    def __init__(self, cpp_lib_path=None, init_new_entities=False):
+        self.init_new_entities = init_new_entities
+        if init_new_entities == False:
+            # C library (Config.py:28-31): defaults to the in-tree MI355X engine
+            if cpp_lib_path is None:
+                cpp_lib_path = _lib.LIB_PATH
+            self.lib = _lib.load(os.path.abspath(cpp_lib_path))
+            # other parameters (Config.py:53-72)
+            self.in_path = None
+            self.out_path = None
+            self.bern = 0
+            self.hidden_size = 64
+            self.ent_size = self.hidden_size
+            self.rel_size = self.hidden_size
+            self.train_times = 0
+            self.margin = 1.0
+            self.nbatches = 0
+            self.negative_ent = 1
+            self.negative_rel = 0
+            self.workThreads = 8
+            self.alpha = 0.001
+            self.exportName = None
+            self.importName = None
+            self.opt_method = "SGD"
+            self.test_link_prediction = False
+            self.test_triple_classification = False
+            self.valid_triple_classification = False
+            # engine-side additions
+            self.seed = 0                 # parameter initialisation seed
+            self.device = "cuda"
+            self.adam_beta1, self.adam_beta2, self.adam_epsilon = 0.9, 0.999, 1e-8  # TF1 AdamOptimizer defaults
+            self.trainModel = None
+            self.global_step = 0
+            self.rank, self.world_size = 0, 1
+            self._pg = None
+
+    # ------------------------------------------------------------------------------------------
+    # Config.py:153-210
+    # ------------------------------------------------------------------------------------------
+    def init(self):
+        '''
+        prepare for train and test
+        '''
+        if self.init_new_entities == False:
+            self.trainModel = None
+            if self.in_path != None:
+                path = self.in_path if self.in_path.endswith("/") else self.in_path + "/"
+                self.lib.kge_clear_error()
+                self.lib.setInPath(path.encode())
+                self.lib.setBern(self.bern)
+                self.lib.setWorkThreads(self.workThreads)
+                self.lib.randReset()
+                self.lib.importTrainFiles()
+                _lib.raise_if_error(self.lib)
+                self.relTotal = self.lib.getRelationTotal()
+                self.entTotal = self.lib.getEntityTotal()
+                self.trainTotal = self.lib.getTrainTotal_()
+                self.testTotal = self.lib.getTestTotal()
+                self.validTotal = self.lib.getValidTotal()
+                self.bt = self.lib.getBatchTotal()
+                self.set_mini_batch()
+                self._alloc_batch_buffers()
+            if self.test_link_prediction or self.test_triple_classification or self.valid_triple_classification:
+                # evaluation inputs (Reader.h:186-449) are outside the hot path built so far
+                pass
+
+    def init_from_arrays(self, ent_total, rel_total, h, t, r, new_batch_total=0):
+        """Same as init() with the training triples (file order) given as arrays instead of files."""
+        h = np.ascontiguousarray(h, dtype=np.int64)
+        t = np.ascontiguousarray(t, dtype=np.int64)
+        r = np.ascontiguousarray(r, dtype=np.int64)
+        self.lib.kge_clear_error()
+        self.lib.setBern(self.bern)
+        self.lib.setWorkThreads(self.workThreads)
+        self.lib.randReset()
+        _lib.check(self.lib.kge_import_train_arrays(ent_total, rel_total, len(h), h.ctypes.data, t.ctypes.data,
+                                                    r.ctypes.data, new_batch_total), self.lib)
+        self.relTotal = self.lib.getRelationTotal()
+        self.entTotal = self.lib.getEntityTotal()
+        self.trainTotal = self.lib.getTrainTotal_()
+        self.testTotal = self.validTotal = 0
+        self.bt = self.lib.getBatchTotal()
+        self.set_mini_batch()
+        self._alloc_batch_buffers()
+
+    def _alloc_batch_buffers(self):
+        # Config.py:172-180
+        self.batch_seq_size = self.batch_size * (1 + self.negative_ent + self.negative_rel)
+        self.batch_h = np.zeros(self.batch_seq_size, dtype=np.int64)
+        self.batch_t = np.zeros(self.batch_seq_size, dtype=np.int64)
+        self.batch_r = np.zeros(self.batch_seq_size, dtype=np.int64)
+        self.batch_y = np.zeros(self.batch_seq_size, dtype=np.float32)
+        self.batch_h_addr = self.batch_h.__array_interface__['data'][0]
+        self.batch_t_addr = self.batch_t.__array_interface__['data'][0]
+        self.batch_r_addr = self.batch_r.__array_interface__['data'][0]
+        self.batch_y_addr = self.batch_y.__array_interface__['data'][0]
+
+    def set_mini_batch(self):
+        '''
+        Set mini batch used during training (Config.py:189-210)
+        '''
+        tot = self.bt if self.bt > 0 else self.trainTotal
+        if self.nbatches > 0:
+            self.batch_size = int(tot / self.nbatches)
+        else:
+            self.batch_size = tot
+            while self.batch_size > 9999:
+                self.batch_size = int(self.batch_size / 10)
+            self.nbatches = int(tot / self.batch_size)
+        print("Batch size is {}".format(self.batch_size))
+        print("Number of batches: {}".format(self.nbatches))
+
+    # ------------------------------------------------------------------------------------------
+    # getters / setters (Config.py:213-340, 425-429)
+    # ------------------------------------------------------------------------------------------
+    def get_ent_total(self):
+        return self.entTotal
+
+    def get_rel_total(self):
+        return self.relTotal
+
+    def set_opt_method(self, method):
+        self.opt_method = method
+
+    def set_test_link_prediction(self, flag):
+        self.test_link_prediction = flag
+
+    def set_test_triple_classification(self, flag):
+        self.test_triple_classification = flag
+
+    def set_valid_triple_classification(self, flag):
+        self.valid_triple_classification = flag
+
+    def set_alpha(self, alpha):
+        self.alpha = alpha
+
+    def set_in_path(self, path):
+        self.in_path = path
+
+    def set_out_files(self, path):
+        self.out_path = path
+
+    def set_bern(self, bern):
+        self.bern = bern
+
+    def set_dimension(self, dim):
+        self.hidden_size = dim
+        self.ent_size = dim
+        self.rel_size = dim
+
+    def set_ent_dimension(self, dim):
+        self.ent_size = dim
+
+    def set_rel_dimension(self, dim):
+        self.rel_size = dim
+
+    def set_train_times(self, times):
+        self.train_times = times
+
+    def set_nbatches(self, nbatches):
+        self.nbatches = nbatches
+
+    def set_margin(self, margin):
+        self.margin = margin
+
+    def set_ent_neg_rate(self, rate):
+        self.negative_ent = rate
+
+    def set_rel_neg_rate(self, rate):
+        self.negative_rel = rate
+
+    def set_import_files(self, path):
+        self.importName = path
+
+    def set_export_files(self, path):
+        self.exportName = path
+
+    def set_work_threads(self, threads):
+        """Number of VIRTUAL sampler threads (rng streams / batch slices, Setting.h:36-39).  The
+        reference hard-codes 8 (Config.py:65); data-parallel ranks split them."""
+        self.workThreads = threads
+
+    def set_model(self, model):
+        self.model = model
+
+    # ------------------------------------------------------------------------------------------
+    # sampling: Base.so-compatible host path (Config.py:343-347)
+    # ------------------------------------------------------------------------------------------
+    def sampling(self):
+        '''
+        Call the engine for batch sampling into the numpy buffers (same bits as the reference)
+        '''
+        self.lib.kge_clear_error()
+        self.lib.sampling(self.batch_h_addr, self.batch_t_addr, self.batch_r_addr, self.batch_y_addr,
+                          self.batch_size, self.negative_ent, self.negative_rel)
+        _lib.raise_if_error(self.lib)
+
+    # ------------------------------------------------------------------------------------------
+    # "session": parameters, optimiser state, train / test steps
+    # ------------------------------------------------------------------------------------------
+    def set_model_and_session(self, model):
+        '''
+        Create the model's device tables and the optimiser state (Config.py:447-461 +
+        distribute_training.create_model, :74-105).
+        '''
+        import torch
+        self.model = model
+        self.trainModel = self.model(config=self, define=True)
+        m = self.trainModel
+        self._desc = m.descriptor()
+        self._tables = [m.parameter_lists[n] for n in m.table_names]
+        self._grads = [torch.zeros_like(t) for t in self._tables]
+        self._adam = self.opt_method in ("Adam", "adam")  # distribute_training.py:95
+        if self._adam:
+            self._adam_m = [torch.zeros_like(t) for t in self._tables]
+            self._adam_v = [torch.zeros_like(t) for t in self._tables]
+            self._beta1_power = np.float32(self.adam_beta1)
+            self._beta2_power = np.float32(self.adam_beta2)
+        self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._tab_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._tables])
+        self._grad_ptrs = _lib.table_ptrs([g.data_ptr() for g in self._grads])
+        self._dev_batch = None
+        self.global_step = 0
+        self._setup_partition()
+
+    # --- data-parallel partition: rank g owns virtual threads [g*W/G, (g+1)*W/G) ---
+    def init_distributed(self, process_group=None):
+        """Join the (already initialised) torch.distributed world: one process per GPU, RCCL."""
+        import torch.distributed as dist
+        self._pg = process_group
+        self.rank = dist.get_rank(process_group)
+        self.world_size = dist.get_world_size(process_group)
+        if self.trainModel is not None:
+            self._setup_partition()
+
+    def _setup_partition(self):
+        from .parallel import thread_range
+        lo, hi = thread_range(self.rank, self.world_size, self.workThreads)
+        self._thread_lo, self._thread_hi = lo, hi
+        first = ctypes.c_int64(0)
+        self._n_local = self.lib.kge_slice_positions(self.batch_size, lo, hi, ctypes.byref(first))
+        self._first_pos = first.value
+
+    def _stream(self):
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _ensure_dev_batch(self, stride):
+        import torch
+        n = stride * (1 + self.negative_ent + self.negative_rel)
+        if self._dev_batch is None or self._dev_batch.shape[1] != n:
+            self._dev_batch = torch.zeros((3, n), dtype=torch.int32, device=self.device)
+        return self._dev_batch
+
+    def sample_device(self):
+        """Sample this rank's slice of the next batch on the device; returns (int32[3,n] tensor, n_pos)."""
+        stride = max(self._n_local, 1)
+        buf = self._ensure_dev_batch(stride)
+        nl = ctypes.c_int64(0)
+        _lib.check(self.lib.kge_sampling_device(buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(),
+                                                self.batch_size, self.negative_ent, self.negative_rel,
+                                                self._thread_lo, self._thread_hi, stride, ctypes.byref(nl),
+                                                self._stream()), self.lib)
+        return buf, nl.value
+
+    def forward_backward(self, dev_batch, n_pos, stride, denom):
+        """Add dLoss/dTables of the batch into the gradient accumulators; loss -> self._loss."""
+        _lib.check(self.lib.kge_forward_backward(ctypes.byref(self._desc), self._tab_ptrs,
+                                                 dev_batch[0].data_ptr(), dev_batch[1].data_ptr(),
+                                                 dev_batch[2].data_ptr(), n_pos,
+                                                 self.negative_ent + self.negative_rel, stride, denom,
+                                                 self._grad_ptrs, self._loss.data_ptr(), self._stream()), self.lib)
+
+    def apply_gradients(self):
+        """GradientDescentOptimizer / AdamOptimizer on the summed gradients (distribute_training.py:95-101)."""
+        st = self._stream()
+        if self._adam:
+            f = np.float32
+            lr_t = f(f(self.alpha) * np.sqrt(f(1) - self._beta2_power, dtype=np.float32) / (f(1) - self._beta1_power))
+            for p, m, v, g in zip(self._tables, self._adam_m, self._adam_v, self._grads):
+                _lib.check(self.lib.kge_adam_update(p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), p.numel(),
+                                                    float(lr_t), self.adam_beta1, self.adam_beta2, self.adam_epsilon,
+                                                    st), self.lib)
+            self._beta1_power = f(self._beta1_power * f(self.adam_beta1))
+            self._beta2_power = f(self._beta2_power * f(self.adam_beta2))
+        else:
+            for p, g in zip(self._tables, self._grads):
+                _lib.check(self.lib.kge_sgd_update(p.data_ptr(), g.data_ptr(), p.numel(), float(self.alpha), st),
+                           self.lib)
+        self.global_step += 1
+
+    def train_step(self, batch_h=None, batch_t=None, batch_r=None, batch_y=None, sync=True):
+        '''
+        Perform a single training step (Config.py:464-475 / distribute_training.py:274-282).
+        With no arguments the batch is sampled on the device; with the reference's four arrays the
+        given batch (layout of Config.batch_h/t/r) is trained on.  Returns the loss (float) when
+        sync=True, else the device scalar.
+        '''
+        import torch
+        n_neg = self.negative_ent + self.negative_rel
+        if batch_h is None:
+            dev, n_pos = self.sample_device()
+            stride = max(self._n_local, 1)
+        else:
+            if self.world_size != 1:
+                raise KgeError("feeding a host batch is single-process only")
+            host = np.stack([np.asarray(batch_h), np.asarray(batch_t), np.asarray(batch_r)]).astype(np.int32)
+            dev = torch.from_numpy(host).to(self.device)
+            n_pos = host.shape[1] // (1 + n_neg)
+            stride = n_pos
+        self.forward_backward(dev, n_pos, stride, self.batch_size * n_neg if batch_h is None else n_pos * n_neg)
+        if self.world_size > 1:
+            from .parallel import allreduce_gradients
+            allreduce_gradients(self._grads + [self._loss], self._pg)
+        self.apply_gradients()
+        self.trainModel.loss = self._loss
+        return float(self._loss.item()) if sync else self._loss
+
+    def test_step(self, test_h, test_t, test_r):
+        '''
+        Score triples with the model's predict op (Config.py:478-488)
+        '''
+        import torch
+        host = np.stack([np.asarray(test_h), np.asarray(test_t), np.asarray(test_r)]).astype(np.int32)
+        dev = torch.from_numpy(host).to(self.device)
+        out = torch.empty(host.shape[1], dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.kge_predict(ctypes.byref(self._desc), self._tab_ptrs, dev[0].data_ptr(), dev[1].data_ptr(),
+                                        dev[2].data_ptr(), host.shape[1], out.data_ptr(), self._stream()), self.lib)
+        self.trainModel.predict = out
+        return out.cpu().numpy()
+
+    # ------------------------------------------------------------------------------------------
+    # parameters by the reference's variable names (Config.py:378-421)
+    # ------------------------------------------------------------------------------------------
+    def get_parameter_lists(self):
+        return self.trainModel.parameter_lists
+
+    def get_parameters_by_name(self, var_name):
+        if var_name in self.trainModel.parameter_lists:
+            return self.trainModel.parameter_lists[var_name].detach().cpu().numpy()
+        return None
+
+    def get_parameters(self, mode="numpy"):
+        res = {}
+        for var_name in self.get_parameter_lists():
+            if mode == "numpy":
+                res[var_name] = self.get_parameters_by_name(var_name)
+            else:
+                res[var_name] = self.get_parameters_by_name(var_name).tolist()
+        return res
+
+    def save_parameters(self, path=None):
+        if path == None:
+            path = self.out_path
+        with open(path, "w") as f:
+            f.write(json.dumps(self.get_parameters("list")))
+
+    def set_parameters_by_name(self, var_name, tensor):
+        import torch
+        if var_name in self.trainModel.parameter_lists:
+            dst = self.trainModel.parameter_lists[var_name]
+            dst.copy_(torch.as_tensor(np.asarray(tensor, dtype=np.float32)).reshape(dst.shape))
+
+    def set_parameters(self, lists):
+        for i in lists:
+            self.set_parameters_by_name(i, lists[i])
+
+    def get_gradients(self):
+        """Current contents of the dense gradient accumulators (zero between steps)."""
+        return {n: g.detach().cpu().numpy() for n, g in zip(self.trainModel.table_names, self._grads)}
+
+    def get_stream_states(self):
+        """rng stream states of the virtual sampler threads (next_random[], Random.h:6)."""
+        out = np.zeros(self.workThreads, dtype=np.uint64)
+        _lib.check(self.lib.kge_get_stream_states(out.ctypes.data, self.workThreads), self.lib)
+        return out

@@ -1,0 +1,88 @@
+"""Model base class: the reference's `Model` protocol (/root/reference/Model.py:5-99) without TensorFlow.
+
+A model is a description of parameter tables plus the id of the fused HIP operator that evaluates
+its loss / gradients / predictions.  The attributes the reference's callers use are kept:
+``parameter_lists`` (name -> tensor, Model.py:74 and TransE.py:23-24), ``loss``, ``predict``,
+``batch_h/t/r/y`` and the (B,1)/(B,N) views of Model.py:62-69 (here as index arithmetic on the flat
+device batch: positive b at [b], negative k of positive b at [B*(k+1)+b]).
+"""
+import numpy as np
+
+from . import _lib
+
+
+def xavier_normal(rng, shape):
+    """tf.contrib.layers.xavier_initializer(uniform=False) as the reference's get_variable calls use
+    it (TransE.py:21-22): truncated normal, stddev sqrt(1.3 * 2 / (fan_in + fan_out)) with
+    fan_in = rows, fan_out = cols, values beyond two stddev re-drawn."""
+    rows, cols = shape
+    std = np.sqrt(2.6 / (rows + cols))
+    a = rng.standard_normal(shape)
+    bad = np.abs(a) > 2.0
+    while bad.any():
+        a[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(a) > 2.0
+    return (a * std).astype(np.float32)
+
+
+class Model(object):
+    model_id = None       # _lib.TRANSE ...
+    table_names = ()      # engine table order (include/kge_mi355.h)
+
+    def get_config(self):
+        return self.config
+
+    # --- Model.py:55-74 -------------------------------------------------------------------------
+    def input_def(self):
+        config = self.config
+        # flat batch of batch_seq_size ids; filled by Config.sampling()/train_step
+        self.batch_h = None
+        self.batch_t = None
+        self.batch_r = None
+        self.batch_y = None
+        self.predict_h = None
+        self.predict_t = None
+        self.predict_r = None
+        self.parameter_lists = {}
+        self.batch_seq_size = getattr(config, "batch_seq_size", None)
+
+    def table_shapes(self):
+        raise NotImplementedError
+
+    def embedding_def(self):
+        """Allocate and initialise the parameter tables on the device (names = checkpoint contract)."""
+        import torch
+        config = self.config
+        rng = np.random.default_rng(getattr(config, "seed", 0))
+        device = getattr(config, "device", "cuda")
+        self.parameter_lists = {}
+        for name in self.table_names:
+            shape = self.table_shapes()[name]
+            self.parameter_lists[name] = torch.from_numpy(xavier_normal(rng, shape)).to(device)
+        for name, t in self.parameter_lists.items():
+            setattr(self, name, t)
+
+    def loss_def(self):
+        self.loss = None   # set by every train step (device scalar)
+
+    def predict_def(self):
+        self.predict = None  # set by Config.test_step
+
+    def descriptor(self):
+        c = self.config
+        ent_dim, rel_dim = self.dims()
+        return _lib.ModelDesc(self.model_id, int(c.negative_rel), int(c.entTotal), int(c.relTotal),
+                              int(ent_dim), int(rel_dim), float(c.margin), 0)
+
+    def dims(self):
+        c = self.config
+        return c.hidden_size, c.hidden_size
+
+    def __init__(self, config, define=False):
+        self.config = config
+        self.parameter_lists = {}
+        if define:
+            self.input_def()
+            self.embedding_def()
+            self.loss_def()
+            self.predict_def()

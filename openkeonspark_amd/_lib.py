@@ -1,0 +1,111 @@
+"""ctypes binding of libkge_mi355.so (include/kge_mi355.h).
+
+The library is the product; this module only locates it, declares its signatures and turns its
+error codes into exceptions.  There is no fallback: if the shared object is missing the import
+fails loudly, and every device entry point raises when no MI355X is usable.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libkge_mi355.so")
+
+TRANSE, TRANSH, TRANSR, TRANSD = 0, 1, 2, 3
+KGE_MAX_TABLES = 4
+
+
+class KgeError(RuntimeError):
+    pass
+
+
+class ModelDesc(ctypes.Structure):
+    """struct kge_model_desc (include/kge_mi355.h)."""
+    _fields_ = [("model", ctypes.c_int32), ("negative_rel", ctypes.c_int32),
+                ("ent_total", ctypes.c_int64), ("rel_total", ctypes.c_int64),
+                ("ent_dim", ctypes.c_int32), ("rel_dim", ctypes.c_int32),
+                ("margin", ctypes.c_float), ("reserved", ctypes.c_int32)]
+
+
+def _declare(L):
+    vp, i64, i32, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float
+    # (1) Base.so-compatible subset, declared the way Config.py:30-31 declares `sampling`
+    L.setInPath.argtypes = [ctypes.c_char_p]
+    L.setOutPath.argtypes = [ctypes.c_char_p]
+    L.setWorkThreads.argtypes = [i64]
+    L.getWorkThreads.restype = i64
+    L.setBern.argtypes = [i64]
+    for fn in ("getEntityTotal", "getRelationTotal", "getTripleTotal", "getTrainTotal", "getTrainTotal_",
+               "getBatchTotal", "getTestTotal", "getValidTotal"):
+        getattr(L, fn).restype = i64
+    L.sampling.argtypes = [vp, vp, vp, vp, i64, i64, i64]
+    # (2) engine
+    L.kge_last_error.restype = ctypes.c_size_t
+    L.kge_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    L.kge_device_available.restype = ctypes.c_int
+    L.kge_version.restype = ctypes.c_char_p
+    L.kge_import_train_arrays.argtypes = [i64, i64, i64, vp, vp, vp, i64]
+    L.kge_index_copy.restype = i64
+    L.kge_index_copy.argtypes = [ctypes.c_char_p, vp, i64]
+    L.kge_get_stream_states.argtypes = [vp, i64]
+    L.kge_set_stream_states.argtypes = [vp, i64]
+    L.kge_sampling_device.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, ctypes.POINTER(i64), vp]
+    L.kge_slice_positions.restype = i64
+    L.kge_slice_positions.argtypes = [i64, i64, i64, ctypes.POINTER(i64)]
+    L.kge_table_shape.argtypes = [ctypes.POINTER(ModelDesc), ctypes.c_int, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    tabs = ctypes.POINTER(vp)
+    L.kge_forward_backward.argtypes = [ctypes.POINTER(ModelDesc), tabs, vp, vp, vp, i64, i64, i64, i64, tabs, vp, vp]
+    L.kge_sgd_update.argtypes = [vp, vp, i64, f32, vp]
+    L.kge_adam_update.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp]
+    L.kge_predict.argtypes = [ctypes.POINTER(ModelDesc), tabs, vp, vp, vp, i64, vp, vp]
+    return L
+
+
+def load(path=None):
+    """Load the engine library.  Raises ImportError when it has not been built."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s not found: build it first (python -c 'import __graft_entry__ as g; g.build()' or "
+            "make -C openkeonspark_amd/csrc).  There is no CPU fallback." % path)
+    return _declare(ctypes.CDLL(path))
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = load()
+    return _LIB
+
+
+def last_error(L=None):
+    L = L or lib()
+    buf = ctypes.create_string_buffer(1024)
+    L.kge_last_error(buf, 1024)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc, L=None):
+    """Raise KgeError for a negative return code of a kge_* call."""
+    if rc is not None and rc < 0:
+        raise KgeError("kge_mi355 error %d: %s" % (rc, last_error(L)))
+    return rc
+
+
+def raise_if_error(L=None):
+    """For the void Base-compatible calls: raise if they recorded an error."""
+    L = L or lib()
+    msg = last_error(L)
+    if msg:
+        L.kge_clear_error()
+        raise KgeError(msg)
+
+
+def table_ptrs(ptrs):
+    """list of up to 4 device addresses (or None) -> (void*)[4]"""
+    arr = (ctypes.c_void_p * KGE_MAX_TABLES)()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr

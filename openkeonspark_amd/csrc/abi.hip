@@ -1,0 +1,306 @@
+// extern "C" surface of libkge_mi355.so (declared in include/kge_mi355.h) and the process-global
+// engine state behind it.
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+
+#include "engine.hpp"
+
+namespace kge {
+
+Engine &engine() {
+    static Engine e;
+    return e;
+}
+
+void set_error(const std::string &msg) {
+    engine().last_error = msg;
+    std::fprintf(stderr, "[kge_mi355] error: %s\n", msg.c_str());
+}
+
+int fail(int code, const std::string &msg) {
+    set_error(msg);
+    return code;
+}
+
+int hip_check(hipError_t e, const char *what) {
+    if (e == hipSuccess) return KGE_OK;
+    return fail(KGE_ERR_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+bool device_ok() {
+    Engine &e = engine();
+    if (e.device_state == 0) {
+        int n = 0;
+        hipError_t rc = hipGetDeviceCount(&n);
+        e.device_state = (rc == hipSuccess && n > 0) ? 1 : -1;
+        if (e.device_state < 0) (void)hipGetLastError();
+    }
+    return e.device_state > 0;
+}
+
+template <typename T>
+static int upload(T *&dst, const void *src, size_t count, const char *what) {
+    if (dst) { (void)hipFree(dst); dst = nullptr; }
+    size_t bytes = sizeof(T) * (count ? count : 1);
+    int rc = hip_check(hipMalloc(&dst, bytes), what);
+    if (rc) return rc;
+    if (count) rc = hip_check(hipMemcpy(dst, src, sizeof(T) * count, hipMemcpyHostToDevice), what);
+    return rc;
+}
+
+int ensure_device_index() {
+    Engine &e = engine();
+    if (!e.index.loaded) return fail(KGE_ERR_NO_DATASET, "no training set imported (importTrainFiles / kge_import_train_arrays)");
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "no usable HIP device: the sampler has no CPU fallback");
+    int rc = KGE_OK;
+    if (!e.dev.uploaded) {
+        const KgIndex &ix = e.index;
+        if ((rc = upload(e.dev.pos, ix.pos.data(), ix.pos.size(), "upload pos"))) return rc;
+        if ((rc = upload(e.dev.grp, ix.grp.data(), ix.grp.size(), "upload grp"))) return rc;
+        if ((rc = upload(e.dev.ht, ix.ht.data(), ix.ht.size(), "upload ht"))) return rc;
+        if ((rc = upload(e.dev.tails_hr, ix.tails_hr.data(), ix.tails_hr.size(), "upload tails"))) return rc;
+        if ((rc = upload(e.dev.heads_tr, ix.heads_tr.data(), ix.heads_tr.size(), "upload heads"))) return rc;
+        if ((rc = upload(e.dev.rels_ht, ix.rels_ht.data(), ix.rels_ht.size(), "upload rels"))) return rc;
+        if ((rc = upload(e.dev.bern_prob, ix.bern_prob.data(), ix.bern_prob.size(), "upload bern"))) return rc;
+        e.dev.uploaded = true;
+    }
+    if ((int64_t)e.streams.size() != e.work_threads) {
+        // setWorkThreads without randReset: the reference would read unallocated memory; give zeros
+        e.streams.assign((size_t)e.work_threads, 0);
+        e.dev.streams_sync = 0;
+    }
+    if (e.dev.streams_sync == 0) {
+        if (e.dev.streams_cap < e.work_threads) {
+            if (e.dev.streams) (void)hipFree(e.dev.streams);
+            e.dev.streams = nullptr;
+            if ((rc = hip_check(hipMalloc(&e.dev.streams, sizeof(uint64_t) * (size_t)e.work_threads), "alloc streams"))) return rc;
+            e.dev.streams_cap = e.work_threads;
+        }
+        if ((rc = hip_check(hipMemcpy(e.dev.streams, e.streams.data(), sizeof(uint64_t) * (size_t)e.work_threads,
+                                      hipMemcpyHostToDevice), "upload streams"))) return rc;
+        e.dev.streams_sync = 1;
+    }
+    return KGE_OK;
+}
+
+static int pull_streams() {
+    Engine &e = engine();
+    if (e.dev.streams_sync == 2) {
+        int rc = hip_check(hipMemcpy(e.streams.data(), e.dev.streams, sizeof(uint64_t) * e.streams.size(),
+                                     hipMemcpyDeviceToHost), "download streams");
+        if (rc) return rc;
+        e.dev.streams_sync = 1;
+    }
+    return KGE_OK;
+}
+
+static void adopt_index(KgIndex &&ix) {
+    Engine &e = engine();
+    e.index = std::move(ix);
+    e.dev.uploaded = false;
+}
+
+}  // namespace kge
+
+using namespace kge;
+
+extern "C" {
+
+void setInPath(char *path) {
+    engine().in_path = path ? path : "";
+    std::printf("Input Files Path : %s\n", engine().in_path.c_str());
+}
+
+void setOutPath(char *path) {
+    engine().out_path = path ? path : "";
+    std::printf("Output Files Path : %s\n", engine().out_path.c_str());
+}
+
+void setWorkThreads(INT threads) { engine().work_threads = threads < 1 ? 1 : threads; }
+INT getWorkThreads(void) { return engine().work_threads; }
+void setBern(INT con) { engine().bern = con; }
+
+void randReset(void) {
+    Engine &e = engine();
+    e.streams.resize((size_t)e.work_threads);
+    for (auto &s : e.streams) s = (uint64_t)(int64_t)e.libc.next();
+    e.dev.streams_sync = 0;
+}
+
+void importTrainFiles(void) {
+    Engine &e = engine();
+    std::printf("The toolkit is importing datasets.\n");
+    int64_t E = 0, R = 0, nb = 0;
+    std::vector<int64_t> h, t, r;
+    std::string err = load_openke_dir(e.in_path, E, R, nb, h, t, r);
+    if (!err.empty()) {
+        std::cout << err << std::endl;  // the reference prints and returns (Reader.h:36-39)
+        set_error(err);
+        return;
+    }
+    std::printf("The total of relations is %ld.\n", (long)R);
+    std::printf("The total of entities is %ld.\n", (long)E);
+    if (nb > 0) std::printf("The total number of new batch triples is: %ld\n", (long)nb);
+    std::printf("The total of train triples is %ld.\n", (long)h.size());
+    KgIndex ix;
+    err = build_index(ix, E, R, nb, (int64_t)h.size(), h.data(), t.data(), r.data());
+    if (!err.empty()) { set_error(err); return; }
+    adopt_index(std::move(ix));
+    std::fflush(stdout);
+}
+
+INT getEntityTotal(void) { return engine().index.ent_total; }
+INT getRelationTotal(void) { return engine().index.rel_total; }
+INT getTripleTotal(void) { return 0; }  // set by importTestFiles in the reference (evaluation, out of scope)
+INT getTrainTotal(void) { return engine().index.train_uniq; }
+INT getTrainTotal_(void) { return engine().index.train_dup; }
+INT getBatchTotal(void) { return engine().index.new_batch; }
+INT getTestTotal(void) { return 0; }
+INT getValidTotal(void) { return 0; }
+
+void sampling(INT *batch_h, INT *batch_t, INT *batch_r, REAL *batch_y, INT batchSize, INT negRate, INT negRelRate) {
+    Engine &e = engine();
+    if (ensure_device_index()) return;
+    if (batchSize <= 0 || negRate < 0 || negRelRate < 0) { set_error("sampling: bad sizes"); return; }
+    const int64_t total = batchSize * (1 + negRate + negRelRate);
+    if (e.dev.stage_cap < total) {
+        if (e.dev.stage_i32) (void)hipFree(e.dev.stage_i32);
+        if (e.dev.stage_i64) (void)hipFree(e.dev.stage_i64);
+        e.dev.stage_i32 = nullptr; e.dev.stage_i64 = nullptr; e.dev.stage_cap = 0;
+        if (hip_check(hipMalloc(&e.dev.stage_i32, sizeof(int32_t) * 3 * (size_t)total), "alloc stage")) return;
+        if (hip_check(hipMalloc(&e.dev.stage_i64, (sizeof(int64_t) * 3 + sizeof(float)) * (size_t)total), "alloc stage")) return;
+        e.dev.stage_cap = total;
+    }
+    int32_t *s = e.dev.stage_i32;
+    // stage arrays are packed at `total` so the widen kernel can address them as [3][total]
+    if (launch_sampler(s, s + total, s + 2 * total, batchSize, negRate, negRelRate, 0, e.work_threads, batchSize, nullptr, nullptr)) return;
+    if (launch_widen(s, e.dev.stage_i64, batchSize, total, nullptr)) return;
+    const int64_t *w = e.dev.stage_i64;
+    if (hip_check(hipMemcpy(batch_h, w, sizeof(int64_t) * total, hipMemcpyDeviceToHost), "copy batch_h")) return;
+    if (hip_check(hipMemcpy(batch_t, w + total, sizeof(int64_t) * total, hipMemcpyDeviceToHost), "copy batch_t")) return;
+    if (hip_check(hipMemcpy(batch_r, w + 2 * total, sizeof(int64_t) * total, hipMemcpyDeviceToHost), "copy batch_r")) return;
+    hip_check(hipMemcpy(batch_y, w + 3 * total, sizeof(float) * total, hipMemcpyDeviceToHost), "copy batch_y");
+}
+
+size_t kge_last_error(char *buf, size_t n) {
+    const std::string &s = engine().last_error;
+    if (buf && n) {
+        size_t k = s.size() < n - 1 ? s.size() : n - 1;
+        std::memcpy(buf, s.data(), k);
+        buf[k] = 0;
+    }
+    return s.size();
+}
+
+void kge_clear_error(void) { engine().last_error.clear(); }
+int kge_device_available(void) { return device_ok() ? 1 : 0; }
+const char *kge_version(void) { return "kge_mi355 0.1 (gfx950)"; }
+
+int kge_import_train_arrays(INT ent_total, INT rel_total, INT n, const INT *h, const INT *t, const INT *r,
+                            INT new_batch_total) {
+    KgIndex ix;
+    std::string err = build_index(ix, ent_total, rel_total, new_batch_total, n, (const int64_t *)h, (const int64_t *)t,
+                                  (const int64_t *)r);
+    if (!err.empty()) return fail(KGE_ERR_BAD_ARG, err);
+    adopt_index(std::move(ix));
+    return KGE_OK;
+}
+
+int64_t kge_index_copy(const char *what, void *dst, int64_t bytes) {
+    const KgIndex &ix = engine().index;
+    if (!ix.loaded) return fail(KGE_ERR_NO_DATASET, "kge_index_copy: no dataset");
+    const void *src = nullptr;
+    int64_t have = 0;
+    std::string w = what ? what : "";
+#define KGE_ARR(name, vec) if (w == name) { src = (vec).data(); have = (int64_t)((vec).size() * sizeof((vec)[0])); }
+    KGE_ARR("tails_hr", ix.tails_hr) KGE_ARR("heads_tr", ix.heads_tr) KGE_ARR("rels_ht", ix.rels_ht)
+    KGE_ARR("pos", ix.pos) KGE_ARR("grp", ix.grp) KGE_ARR("ht", ix.ht)
+    KGE_ARR("left_mean", ix.left_mean) KGE_ARR("right_mean", ix.right_mean) KGE_ARR("bern_prob", ix.bern_prob)
+#undef KGE_ARR
+    if (!src && have == 0 && w != "tails_hr" && w != "heads_tr" && w != "rels_ht" && w != "pos" && w != "grp" && w != "ht" &&
+        w != "left_mean" && w != "right_mean" && w != "bern_prob")
+        return fail(KGE_ERR_BAD_ARG, "kge_index_copy: unknown array " + w);
+    if (dst && bytes > 0 && have > 0) std::memcpy(dst, src, (size_t)(bytes < have ? bytes : have));
+    return have;
+}
+
+int kge_get_stream_states(uint64_t *dst, INT n) {
+    Engine &e = engine();
+    int rc = pull_streams();
+    if (rc) return rc;
+    for (INT i = 0; i < n && i < (INT)e.streams.size(); i++) dst[i] = e.streams[(size_t)i];
+    return KGE_OK;
+}
+
+int kge_set_stream_states(const uint64_t *src, INT n) {
+    Engine &e = engine();
+    if (n != e.work_threads) return fail(KGE_ERR_BAD_ARG, "kge_set_stream_states: n must equal workThreads");
+    e.streams.assign(src, src + n);
+    e.dev.streams_sync = 0;
+    return KGE_OK;
+}
+
+INT kge_slice_positions(INT batchSize, INT thread_lo, INT thread_hi, INT *first_position) {
+    const int64_t W = engine().work_threads;
+    if (batchSize <= 0 || thread_lo < 0 || thread_hi > W || thread_lo >= thread_hi) {
+        if (first_position) *first_position = 0;
+        return 0;
+    }
+    int64_t lo, hi, tmp;
+    thread_slice(batchSize, W, thread_lo, lo, tmp);
+    thread_slice(batchSize, W, thread_hi - 1, tmp, hi);
+    if (first_position) *first_position = lo;
+    return hi - lo;
+}
+
+int kge_sampling_device(int32_t *d_h, int32_t *d_t, int32_t *d_r, INT batchSize, INT negRate, INT negRelRate,
+                        INT thread_lo, INT thread_hi, INT out_stride, INT *n_local, void *stream) {
+    int64_t nl = 0;
+    int rc = launch_sampler(d_h, d_t, d_r, batchSize, negRate, negRelRate, thread_lo, thread_hi, out_stride, &nl,
+                            (hipStream_t)stream);
+    if (n_local) *n_local = nl;
+    return rc;
+}
+
+int kge_table_shape(const kge_model_desc *m, int table, int64_t *rows, int64_t *cols) {
+    if (!m || !rows || !cols) return KGE_ERR_BAD_ARG;
+    *rows = 0; *cols = 0;
+    switch (table) {
+        case 0: *rows = m->ent_total; *cols = m->ent_dim; break;
+        case 1: *rows = m->rel_total; *cols = m->rel_dim; break;
+        case 2:
+            if (m->model == KGE_TRANSH || m->model == KGE_TRANSD) { *rows = m->rel_total; *cols = m->rel_dim; }
+            if (m->model == KGE_TRANSR) { *rows = m->rel_total; *cols = (int64_t)m->ent_dim * m->rel_dim; }
+            break;
+        case 3:
+            if (m->model == KGE_TRANSD) { *rows = m->ent_total; *cols = m->ent_dim; }
+            break;
+        default: return KGE_ERR_BAD_ARG;
+    }
+    return KGE_OK;
+}
+
+int kge_forward_backward(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES], const int32_t *d_h,
+                         const int32_t *d_t, const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom,
+                         float *const grads[KGE_MAX_TABLES], float *d_loss, void *stream) {
+    if (!m || !tables || !grads || !d_loss) return fail(KGE_ERR_BAD_ARG, "kge_forward_backward: null argument");
+    return launch_forward_backward(*m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, grads, d_loss, (hipStream_t)stream);
+}
+
+int kge_sgd_update(float *d_p, float *d_g, int64_t n, float lr, void *stream) {
+    return launch_sgd(d_p, d_g, n, lr, (hipStream_t)stream);
+}
+
+int kge_adam_update(float *d_p, float *d_m, float *d_v, float *d_g, int64_t n, float lr_t, float beta1, float beta2,
+                    float eps, void *stream) {
+    return launch_adam(d_p, d_m, d_v, d_g, n, lr_t, beta1, beta2, eps, (hipStream_t)stream);
+}
+
+int kge_predict(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES], const int32_t *d_h,
+                const int32_t *d_t, const int32_t *d_r, INT n, float *d_out, void *stream) {
+    if (!m || !tables || !d_out) return fail(KGE_ERR_BAD_ARG, "kge_predict: null argument");
+    return launch_predict(*m, tables, d_h, d_t, d_r, n, d_out, (hipStream_t)stream);
+}
+
+}  // extern "C"

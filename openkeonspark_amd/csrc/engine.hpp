@@ -1,0 +1,75 @@
+// Process-global engine state shared by the translation units of libkge_mi355.so.
+//
+// Like the reference's Base.so (base/Reader.h:9-24, base/Setting.h:9-10,34,50-61) the library
+// holds ONE dataset per process.  The host index lives in `KgIndex`; its device mirror is uploaded
+// lazily on first device use so that the loader and getters also work on a box without a GPU
+// (where every device entry point fails with KGE_ERR_NO_DEVICE -- there is no CPU fallback).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kge_mi355.h"
+#include "kg_index.hpp"
+
+namespace kge {
+
+struct DeviceIndex {
+    bool uploaded = false;
+    int4 *pos = nullptr;      // [train_dup]
+    int4 *grp = nullptr;      // [train_dup]
+    int2 *ht = nullptr;       // [train_dup]
+    int32_t *tails_hr = nullptr, *heads_tr = nullptr, *rels_ht = nullptr;  // [train_uniq]
+    float *bern_prob = nullptr;                                            // [rel_total]
+    uint64_t *streams = nullptr;                                           // [work_threads]
+    int64_t streams_cap = 0;
+    int streams_sync = 0;  // 0: host copy newer (upload before use), 1: in sync, 2: device copy newer
+    // staging for the Base.so-compatible host-buffer `sampling`
+    int32_t *stage_i32 = nullptr;    // 3 * cap int32
+    int64_t *stage_i64 = nullptr;    // 3 * cap int64 followed by cap floats
+    int64_t stage_cap = 0;
+    float *loss_partials = nullptr;  // per-block partial losses
+};
+
+struct Engine {
+    std::mutex mu;
+    std::string in_path = "../data/FB15K/";   // Setting.h:9
+    std::string out_path = "../data/FB15K/";  // Setting.h:10
+    int64_t work_threads = 1;                 // Setting.h:34
+    int64_t bern = 0;                         // Setting.h:108
+    KgIndex index;
+    LibcRand libc;
+    std::vector<uint64_t> streams;  // host view of next_random[] (Random.h:6)
+    LcgJumpTable jump = make_jump_table();
+    DeviceIndex dev;
+    std::string last_error;
+    int device_state = 0;  // 0 unknown, 1 ok, -1 none
+};
+
+Engine &engine();
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+bool device_ok();
+// uploads index / rng streams if needed; returns KGE_OK or an error code
+int ensure_device_index();
+int hip_check(hipError_t e, const char *what);
+
+constexpr int kMaxLossBlocks = 4096;
+
+// ---- launchers implemented in the .hip files ------------------------------------------------
+int launch_sampler(int32_t *d_h, int32_t *d_t, int32_t *d_r, int64_t B, int64_t neg, int64_t negrel, int64_t thread_lo,
+                   int64_t thread_hi, int64_t out_stride, int64_t *n_local, hipStream_t stream);
+int launch_widen(const int32_t *src3, int64_t *dst3_and_y, int64_t B, int64_t total, hipStream_t stream);
+int launch_forward_backward(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
+                            const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride, int64_t denom,
+                            float *const grads[4], float *d_loss, hipStream_t stream);
+int launch_predict(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
+                   const int32_t *d_r, int64_t n, float *d_out, hipStream_t stream);
+int launch_sgd(float *p, float *g, int64_t n, float lr, hipStream_t stream);
+int launch_adam(float *p, float *m, float *v, float *g, int64_t n, float lr_t, float b1, float b2, float eps,
+                hipStream_t stream);
+
+}  // namespace kge

@@ -1,0 +1,94 @@
+// Optimiser sweeps over a dense table and its dense summed-gradient accumulator.
+//
+// The reference applies `GradientDescentOptimizer` / `AdamOptimizer` to IndexedSlices
+// (distribute_training.py:95-101).  SGD: scatter_sub of lr*g, duplicates accumulating -- i.e.
+// p -= lr * (summed g).  Adam (TF1 _apply_sparse_shared): m and v decay for EVERY row, touched rows
+// receive (1-beta)*g, then EVERY row moves -- a dense sweep of three tables per step (SURVEY.md
+// A13).  Both are single streaming passes here: 16 B per lane, grid-stride, the accumulator is
+// re-zeroed in the same pass so no separate memset is needed.  HBM-bound by construction:
+// SGD 16 B/element (read p,g; write p,g), Adam 32 B/element.
+#include "engine.hpp"
+
+namespace kge {
+
+__global__ __launch_bounds__(256) void sgd_kernel(float *__restrict__ p, float *__restrict__ g, long long n, float lr) {
+    const long long n4 = n >> 2;
+    float4 *p4 = reinterpret_cast<float4 *>(p);
+    float4 *g4 = reinterpret_cast<float4 *>(g);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 gv = g4[i];
+        if (gv.x != 0.f || gv.y != 0.f || gv.z != 0.f || gv.w != 0.f) {  // untouched rows: p - lr*0 == p, skip the stores
+            float4 pv = p4[i];
+            pv.x -= lr * gv.x; pv.y -= lr * gv.y; pv.z -= lr * gv.z; pv.w -= lr * gv.w;
+            p4[i] = pv;
+            g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        p[i] -= lr * g[i];
+        g[i] = 0.f;
+    }
+}
+
+__device__ __forceinline__ void adam_one(float &p, float &m, float &v, float g, float lr_t, float b1, float b2, float eps) {
+    // TF1 op order, each product rounded before the add (no fma contraction across the ops)
+    float mi = __fmul_rn(m, b1);
+    float vi = __fmul_rn(v, b2);
+    if (g != 0.f) {
+        mi = __fadd_rn(mi, __fmul_rn(g, 1.0f - b1));
+        vi = __fadd_rn(vi, __fmul_rn(__fmul_rn(g, g), 1.0f - b2));
+    }
+    m = mi; v = vi;
+    p = __fsub_rn(p, __fdiv_rn(__fmul_rn(lr_t, mi), __fadd_rn(__fsqrt_rn(vi), eps)));
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
+                                                   float *__restrict__ g, long long n, float lr_t, float b1, float b2,
+                                                   float eps) {
+    const long long n4 = n >> 2;
+    float4 *p4 = reinterpret_cast<float4 *>(p), *m4 = reinterpret_cast<float4 *>(m);
+    float4 *v4 = reinterpret_cast<float4 *>(v), *g4 = reinterpret_cast<float4 *>(g);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pv = p4[i], mv = m4[i], vv = v4[i], gv = g4[i];
+        adam_one(pv.x, mv.x, vv.x, gv.x, lr_t, b1, b2, eps);
+        adam_one(pv.y, mv.y, vv.y, gv.y, lr_t, b1, b2, eps);
+        adam_one(pv.z, mv.z, vv.z, gv.z, lr_t, b1, b2, eps);
+        adam_one(pv.w, mv.w, vv.w, gv.w, lr_t, b1, b2, eps);
+        p4[i] = pv; m4[i] = mv; v4[i] = vv;
+        if (gv.x != 0.f || gv.y != 0.f || gv.z != 0.f || gv.w != 0.f) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        adam_one(p[i], m[i], v[i], g[i], lr_t, b1, b2, eps);
+        g[i] = 0.f;
+    }
+}
+
+static unsigned sweep_blocks(long long n) {
+    long long b = ((n >> 2) + 255) / 256;
+    if (b > 2048) b = 2048;  // 8 blocks per CU, grid-stride beyond that
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+int launch_sgd(float *p, float *g, int64_t n, float lr, hipStream_t stream) {
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_sgd_update: no usable HIP device");
+    if (n <= 0) return KGE_OK;
+    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g)) & 15) return fail(KGE_ERR_BAD_ARG, "tables must be 16-byte aligned");
+    hipLaunchKernelGGL(sgd_kernel, dim3(sweep_blocks(n)), dim3(256), 0, stream, p, g, (long long)n, lr);
+    return hip_check(hipGetLastError(), "sgd launch");
+}
+
+int launch_adam(float *p, float *m, float *v, float *g, int64_t n, float lr_t, float b1, float b2, float eps,
+                hipStream_t stream) {
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_adam_update: no usable HIP device");
+    if (n <= 0) return KGE_OK;
+    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+         reinterpret_cast<uintptr_t>(v)) & 15)
+        return fail(KGE_ERR_BAD_ARG, "tables must be 16-byte aligned");
+    hipLaunchKernelGGL(adam_kernel, dim3(sweep_blocks(n)), dim3(256), 0, stream, p, m, v, g, (long long)n, lr_t, b1, b2, eps);
+    return hip_check(hipGetLastError(), "adam launch");
+}
+
+}  // namespace kge

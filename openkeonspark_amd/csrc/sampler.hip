@@ -1,0 +1,172 @@
+// Device negative sampler: one GPU thread per SCORED TRIPLE (positive or negative).
+//
+// The reference fills a batch with `workThreads` pthreads, each walking its slice sequentially on
+// its own LCG stream (base/Base.cpp:74-143, base/Random.h:16-19).  Every positive consumes a FIXED
+// number of draws (1 + 2*negRate + negRelRate), so the state in front of any draw is a jump-ahead
+// of the slice's start state; that turns the sequential walk into B*(1+n+nr) independent threads
+// whose output is bit-identical to the reference.  The filter is the reference's: draw k uniformly
+// from the complement of the known tails / heads / relations (base/Corrupt.h:7-101), here as one
+// monotone search over a flat int32 group (the two group-locating searches were done at load time,
+// kg_index.hpp).
+#include "engine.hpp"
+
+namespace kge {
+
+__constant__ LcgJumpTable c_jump;
+static bool g_jump_uploaded = false;
+
+struct SamplerArgs {
+    const int4 *pos;
+    const int4 *grp;
+    const int2 *ht;
+    const int32_t *tails_hr, *heads_tr, *rels_ht;
+    const float *bern_prob;
+    const uint64_t *streams;
+    int32_t *out_h, *out_t, *out_r;
+    long long per_thread;  // positions per virtual thread: B/W, or B/W+1 when W does not divide B
+    long long pos_lo;      // first global batch position written by this launch
+    long long n_local;     // positions written by this launch
+    long long out_stride;
+    long long train_dup, new_batch;
+    int ent_total, rel_total;
+    int neg, negrel, bern;
+};
+
+__device__ __forceinline__ uint64_t lcg_step(uint64_t s) { return s * kLcgMul + kLcgAdd; }
+
+__device__ __forceinline__ uint64_t lcg_skip(uint64_t s, uint64_t n) {
+    for (int j = 0; n != 0; ++j, n >>= 1)
+        if (n & 1) s = c_jump.mulA[j] * s + c_jump.addC[j];
+    return s;
+}
+
+// Corrupt.h:25-36 in closed form: the tmp-th id (0-based) that is NOT in the strictly increasing
+// list vals[0..len) is tmp + #{j : vals[j] - j <= tmp}; the predicate is monotone in j.
+__device__ __forceinline__ int filtered_pick(const int32_t *__restrict__ vals, int len, long long tmp) {
+    int lo = 0, hi = len;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if ((long long)vals[mid] - mid <= tmp) lo = mid + 1; else hi = mid;
+    }
+    return (int)(tmp + lo);
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(SamplerArgs a) {
+    const long long per_pos = 1 + a.neg + a.negrel;
+    const long long total = a.n_local * per_pos;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long k = idx / a.n_local;          // 0 = positive, 1..neg entity negatives, then relation negatives
+        const long long b = idx - k * a.n_local;      // local batch position
+        const long long p = a.pos_lo + b;             // global batch position
+        const long long id = p / a.per_thread;        // owning virtual thread (Base.cpp:85-92)
+        const long long off = p - id * a.per_thread;  // index inside its slice
+        const unsigned long long draws = 1ull + 2ull * a.neg + a.negrel;
+        uint64_t s = lcg_skip(a.streams[id], (unsigned long long)off * draws);
+        s = lcg_step(s);  // Base.cpp:101-106: which training triple
+        long long i = a.new_batch > 0 ? (long long)(s % (unsigned long long)a.new_batch) + (a.train_dup - a.new_batch)
+                                      : (long long)(s % (unsigned long long)a.train_dup);
+        const int4 tr = a.pos[i];  // (h, t, r, -)
+        int oh = tr.x, ot = tr.y, orr = tr.z;
+        if (k >= 1 && k <= a.neg) {
+            s = lcg_skip(s, 2ull * (unsigned long long)(k - 1));
+            s = lcg_step(s);  // Base.cpp:118: head-or-tail coin, compared in float
+            const float prob = a.bern ? a.bern_prob[orr] : 500.0f;
+            const bool keep_head = (float)(s % 1000ull) < prob;
+            s = lcg_step(s);  // Corrupt.h:25: the one draw of the corruption
+            const int4 g = a.grp[i];
+            if (keep_head) {  // corrupt_head(h, r): new TAIL outside tails(h,r)
+                long long tmp = (long long)(s % (unsigned long long)(a.ent_total - g.y));
+                ot = filtered_pick(a.tails_hr + g.x, g.y, tmp);
+            } else {          // corrupt_tail(t, r): new HEAD outside heads(t,r)
+                long long tmp = (long long)(s % (unsigned long long)(a.ent_total - g.w));
+                oh = filtered_pick(a.heads_tr + g.z, g.w, tmp);
+            }
+        } else if (k > a.neg) {  // Base.cpp:133-139: corrupt_rel(h, t)
+            s = lcg_skip(s, 2ull * a.neg + (unsigned long long)(k - 1 - a.neg));
+            s = lcg_step(s);
+            const int2 g = a.ht[i];
+            long long tmp = (long long)(s % (unsigned long long)(a.rel_total - g.y));
+            orr = filtered_pick(a.rels_ht + g.x, g.y, tmp);
+        }
+        const long long o = b + k * a.out_stride;
+        a.out_h[o] = oh; a.out_t[o] = ot; a.out_r[o] = orr;
+    }
+}
+
+// After a batch every stream has moved by (slice length) * (draws per positive).
+__global__ void advance_streams_kernel(uint64_t *streams, long long W, long long B, long long per_thread,
+                                       unsigned long long draws) {
+    long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= W) return;
+    long long lef = id * per_thread, rig = lef + per_thread;
+    if (rig > B) rig = B;
+    if (lef > B) lef = B;
+    streams[id] = lcg_skip(streams[id], (unsigned long long)(rig - lef) * draws);
+}
+
+// int32 device batch -> the reference's int64 h/t/r + float y host layout (Base.cpp:109-139: y=+1 for
+// the B positives, -1 for every negative).
+__global__ void widen_kernel(const int32_t *__restrict__ src, long long *__restrict__ dst, float *__restrict__ y,
+                             long long B, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        dst[i] = src[i];
+        dst[total + i] = src[total + i];
+        dst[2 * total + i] = src[2 * total + i];
+        y[i] = i < B ? 1.0f : -1.0f;
+    }
+}
+
+int launch_sampler(int32_t *d_h, int32_t *d_t, int32_t *d_r, int64_t B, int64_t neg, int64_t negrel, int64_t thread_lo,
+                   int64_t thread_hi, int64_t out_stride, int64_t *n_local_out, hipStream_t stream) {
+    Engine &e = engine();
+    int rc = ensure_device_index();
+    if (rc) return rc;
+    const int64_t W = e.work_threads;
+    if (B <= 0 || neg < 0 || negrel < 0 || thread_lo < 0 || thread_hi > W || thread_lo > thread_hi)
+        return fail(KGE_ERR_BAD_ARG, "kge_sampling_device: bad batch/thread range");
+    if (e.index.train_dup <= 0) return fail(KGE_ERR_NO_DATASET, "sampling: empty training set");
+    if (!g_jump_uploaded) {
+        rc = hip_check(hipMemcpyToSymbol(HIP_SYMBOL(c_jump), &e.jump, sizeof(LcgJumpTable)), "upload jump table");
+        if (rc) return rc;
+        g_jump_uploaded = true;
+    }
+    int64_t lo, hi, tmp;
+    if (thread_lo == thread_hi) { lo = hi = 0; }
+    else { thread_slice(B, W, thread_lo, lo, tmp); thread_slice(B, W, thread_hi - 1, tmp, hi); }
+    const int64_t n_local = hi - lo;
+    if (n_local_out) *n_local_out = n_local;
+    if (out_stride < n_local) return fail(KGE_ERR_BAD_ARG, "kge_sampling_device: out_stride smaller than the slice");
+    const int64_t per_thread = (B % W == 0) ? B / W : B / W + 1;
+    if (n_local > 0) {
+        SamplerArgs a;
+        a.pos = e.dev.pos; a.grp = e.dev.grp; a.ht = e.dev.ht;
+        a.tails_hr = e.dev.tails_hr; a.heads_tr = e.dev.heads_tr; a.rels_ht = e.dev.rels_ht;
+        a.bern_prob = e.dev.bern_prob; a.streams = e.dev.streams;
+        a.out_h = d_h; a.out_t = d_t; a.out_r = d_r;
+        a.per_thread = per_thread; a.pos_lo = lo; a.n_local = n_local; a.out_stride = out_stride;
+        a.train_dup = e.index.train_dup; a.new_batch = e.index.new_batch;
+        a.ent_total = (int)e.index.ent_total; a.rel_total = (int)e.index.rel_total;
+        a.neg = (int)neg; a.negrel = (int)negrel; a.bern = e.bern ? 1 : 0;
+        const int64_t total = n_local * (1 + neg + negrel);
+        int64_t blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(sample_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    }
+    hipLaunchKernelGGL(advance_streams_kernel, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, stream, e.dev.streams,
+                       (long long)W, (long long)B, (long long)per_thread,
+                       (unsigned long long)(1 + 2 * neg + negrel));
+    e.dev.streams_sync = 2;  // device copy is now the newer one
+    return hip_check(hipGetLastError(), "sampler launch");
+}
+
+int launch_widen(const int32_t *src3, int64_t *dst3_and_y, int64_t B, int64_t total, hipStream_t stream) {
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(widen_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src3, (long long *)dst3_and_y,
+                       (float *)(dst3_and_y + 3 * total), (long long)B, (long long)total);
+    return hip_check(hipGetLastError(), "widen launch");
+}
+
+}  // namespace kge

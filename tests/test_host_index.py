@@ -1,0 +1,139 @@
+"""CPU-side checks of the engine library: it loads, exports the whole C ABI, and its host loader /
+filter index agrees with the reference-pinned oracle.  No compute entry point is called here."""
+import ctypes
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from oracle import oracle
+from openkeonspark_amd import _lib
+from openkeonspark_amd.Config import Config
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "kge_mi355.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)
+    skip = {"defined", "sizeof"}
+    return sorted({n for n in names if n not in skip and not n.isupper()})
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    syms = declared_symbols()
+    assert "sampling" in syms and "kge_forward_backward" in syms and len(syms) >= 30
+    for s in syms:
+        assert hasattr(L, s), s
+
+
+def test_base_so_hot_path_names_present():
+    # the names Config.py:30-31,160-170,347 binds
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for s in ["setInPath", "setOutPath", "setWorkThreads", "getWorkThreads", "setBern", "randReset", "importTrainFiles",
+              "getEntityTotal", "getRelationTotal", "getTripleTotal", "getTrainTotal", "getTrainTotal_", "getTestTotal",
+              "getValidTotal", "getBatchTotal", "sampling"]:
+        assert hasattr(L, s), s
+
+
+def index_array(L, name, dtype, cols=None):
+    nbytes = L.kge_index_copy(name.encode(), None, 0)
+    assert nbytes >= 0
+    a = np.zeros(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+    L.kge_index_copy(name.encode(), a.ctypes.data, nbytes)
+    return a.reshape(-1, cols) if cols else a
+
+
+@pytest.mark.parametrize("kg_name", ["kg_tiny", "kg_small", "kg_incr"])
+def test_host_index_matches_oracle(kg_name):
+    con = Config()
+    con.set_in_path(os.path.join(GOLDEN, kg_name))
+    con.set_work_threads(3)
+    con.init()
+    kg = oracle.KG(os.path.join(GOLDEN, kg_name), work_threads=3)
+    z = np.load(os.path.join(GOLDEN, "%s_W3_bern0.npz" % kg_name))
+    L = con.lib
+    assert [L.getEntityTotal(), L.getRelationTotal(), L.getTrainTotal(), L.getTrainTotal_(), L.getBatchTotal()] \
+        == z["totals"].tolist()
+    assert con.trainTotal == kg.trainTotal_ and con.bt == kg.batchTotal
+    assert np.array_equal(index_array(L, "tails_hr", np.int32), z["by_head"][:, 2])
+    assert np.array_equal(index_array(L, "heads_tr", np.int32), z["by_tail"][:, 0])
+    assert np.array_equal(index_array(L, "rels_ht", np.int32), z["by_rel"][:, 1])
+    assert index_array(L, "left_mean", np.float32).tobytes() == z["left_mean"].tobytes()
+    assert index_array(L, "right_mean", np.float32).tobytes() == z["right_mean"].tobytes()
+    # every file-order triple's groups contain exactly the known tails / heads / relations
+    pos = index_array(L, "pos", np.int32, 4)
+    grp = index_array(L, "grp", np.int32, 4)
+    ht = index_array(L, "ht", np.int32, 2)
+    tails, heads, rels = (index_array(L, n, np.int32) for n in ("tails_hr", "heads_tr", "rels_ht"))
+    uniq = {(int(a), int(b), int(c)) for a, b, c in z["by_head"]}  # (h, r, t)
+    for i in range(0, len(pos), max(1, len(pos) // 200)):
+        h, t, r, _ = pos[i]
+        assert set(tails[grp[i, 0]:grp[i, 0] + grp[i, 1]]) == {tt for (hh, rr, tt) in uniq if hh == h and rr == r}
+        assert set(heads[grp[i, 2]:grp[i, 2] + grp[i, 3]]) == {hh for (hh, rr, tt) in uniq if tt == t and rr == r}
+        assert set(rels[ht[i, 0]:ht[i, 0] + ht[i, 1]]) == {rr for (hh, rr, tt) in uniq if hh == h and tt == t}
+    # Base.cpp:117 probability, float arithmetic as written there
+    lm, rm = z["left_mean"], z["right_mean"]
+    with np.errstate(invalid="ignore"):
+        want = (np.float32(1000) * rm) / (rm + lm)
+    got = index_array(L, "bern_prob", np.float32)
+    ok = ~np.isnan(want)
+    assert np.array_equal(got[ok], want[ok]) and np.isnan(got[~ok]).all()
+
+
+def test_missing_directory_is_reported_not_fatal():
+    con = Config()
+    con.set_in_path("/nonexistent/dir")
+    with pytest.raises(_lib.KgeError, match="does not exist"):  # reference prints the same text (Reader.h:36-39)
+        con.init()
+
+
+def test_out_of_range_ids_are_rejected():
+    con = Config()
+    with pytest.raises(_lib.KgeError, match="out of range"):
+        con.init_from_arrays(5, 2, [0, 7], [1, 2], [0, 1])
+
+
+def test_mini_batch_rule_and_buffers():
+    # Config.py:189-210: auto batch = total divided by 10 until <= 9999; nbatches = int(total / batch)
+    con = Config()
+    h = np.arange(27211) % 50
+    con.init_from_arrays(50, 3, h, (h + 1) % 50, h % 3)
+    assert (con.batch_size, con.nbatches) == (2721, 10)
+    con2 = Config()
+    con2.set_nbatches(4)
+    con2.set_ent_neg_rate(25)
+    con2.init_from_arrays(50, 3, h, (h + 1) % 50, h % 3)
+    assert con2.batch_size == 6802 and con2.batch_seq_size == 6802 * 26
+    assert con2.batch_h.dtype == np.int64 and con2.batch_y.dtype == np.float32 and len(con2.batch_h) == 6802 * 26
+
+
+def test_slice_positions_tile_the_batch():
+    from openkeonspark_amd.parallel import slice_positions, thread_range
+    con = Config()
+    for W in (1, 3, 8, 16):
+        con.set_work_threads(W)
+        con.lib.setWorkThreads(W)
+        for B in (1, 7, 50, 64, 2721, 68028):
+            covered = 0
+            for lo in range(W):
+                first = ctypes.c_int64()
+                n = con.lib.kge_slice_positions(B, lo, lo + 1, ctypes.byref(first))
+                assert (first.value, n) == slice_positions(B, W, lo, lo + 1)
+                if n:
+                    assert first.value == covered
+                covered += n
+            assert covered == B
+            for G in (1, 2, 4, 8):
+                if W % G:
+                    continue
+                tot = 0
+                for g in range(G):
+                    a, b = thread_range(g, G, W)
+                    f, n = slice_positions(B, W, a, b)
+                    assert n == 0 or f == tot
+                    tot += n
+                assert tot == B
