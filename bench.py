@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: positive triples/s of the training step (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): FB15k-237-shaped
+synthetic knowledge graph (14 541 entities, 237 relations, 272 115 train triples; the reference
+ships no data), TransE dim=200, Adam with the reference's TF1 semantics (dense sweep), 25
+negatives per positive with Bernoulli head/tail skew, margin 1.0.  Arithmetic and storage are fp32
+(the parity mode; BASELINE's "bf16" storage would be a precision reduction and is not used here).
+
+One "step" = what the reference does per loop iteration (distribute_training.py:274-282):
+sample a batch (on the device), forward, backward, optimiser update -- all inside the timed region,
+inputs resident in HBM.  N GPUs = N processes, rank g owns the virtual sampler threads
+[g*8/N, (g+1)*8/N); gradients are all-reduced over RCCL.  Per-GPU batch is held at ~34 014 positives
+(nbatches = 8/N), so scaling is weak.
+
+python bench.py --gpus N --steps K --warmup W      (torchrun-launched for N > 1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DIM = 200
+NEG = 25
+WORK_THREADS = 8
+PER_GPU_NBATCHES = 8     # nbatches = 8/N  -> per-GPU batch 34 014, global batch 34 014 * N
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def algorithmic_bytes_per_positive(n_neg, dim, elem=4):
+    """SURVEY.md 8(d), TransE: U = 3+n unique rows per positive group.  The fused forward/backward
+    kernel reads each of them once (gather, U*D*s) and adds one gradient row for each (U*D*s), plus the
+    int32 (h,t,r) of the 1+n scored triples."""
+    u = 3 + n_neg
+    return 2 * u * dim * elem + 12 * (1 + n_neg)
+
+
+def cpu_baseline(fb_dir, seconds=12.0):
+    """The CPU oracle (C restatement of the reference path: sampler + TransE fwd/bwd + TF1 Adam) timed
+    on this host, all cores for the model part, on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import oracle
+    threads = oracle.lib().orc_max_threads()
+    kg = oracle.KG(fb_dir, work_threads=WORK_THREADS, bern=1)
+    B = 4096
+    m = oracle.Model("transe", kg.entTotal, kg.relTotal, DIM, margin=1.0, seed=0)
+    # warm-up
+    bh, bt, br, _ = kg.sampling(B, NEG, 0)
+    m.adam_step(bh, bt, br, B, NEG, 0.001, nthreads=threads)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        bh, bt, br, _ = kg.sampling(B, NEG, 0)
+        m.adam_step(bh, bt, br, B, NEG, 0.001, nthreads=threads)
+        steps += 1
+        if time.perf_counter() - t0 >= seconds or steps >= 200:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "positive triples/s", "cores": int(threads), "kind": "port",
+            "sample": "%d steps of B=%d positives x %d negatives, TransE dim=%d, TF1 Adam; oracle/kge_oracle.c "
+                      "(sampler 1 thread + OpenMP forward/backward)" % (steps, B, NEG, DIM)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torchrun launch with that many ranks" % args.gpus)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from openkeonspark_amd.synthetic import make_dataset, FB15K237
+    from openkeonspark_amd import Config, TransE
+
+    if rank == 0:
+        fb_dir = make_dataset("/tmp/okes_fb15k237_shaped", FB15K237)
+    if world > 1:
+        dist.barrier()
+    fb_dir = make_dataset("/tmp/okes_fb15k237_shaped", FB15K237)
+
+    if PER_GPU_NBATCHES % world:
+        raise SystemExit("--gpus must divide %d" % PER_GPU_NBATCHES)
+    # the reference-style prints (Python "Batch size is ..." and the C library's "Input Files Path
+    # : ...") must not pollute the single JSON line: park fd 1 on /dev/null while setting up
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    devnull_fd = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull_fd, 1)
+    con = Config()
+    con.device = "cuda:%d" % local_rank
+    con.set_in_path(fb_dir)
+    con.set_work_threads(WORK_THREADS)
+    con.set_bern(1)
+    con.set_dimension(DIM)
+    con.set_nbatches(PER_GPU_NBATCHES // world)
+    con.set_ent_neg_rate(NEG)
+    con.set_rel_neg_rate(0)
+    con.set_margin(1.0)
+    con.set_alpha(0.001)
+    con.set_opt_method("Adam")
+    con.init()
+    con.set_model_and_session(TransE)
+    if world > 1:
+        con.init_distributed()
+    sys.stdout.flush()
+    con.lib.kge_clear_error()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    os.dup2(saved_fd, 1)
+    os.close(saved_fd)
+    os.close(devnull_fd)
+    B = con.batch_size
+    n_local = con._n_local
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        con.train_step(sync=False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        con.train_step(sync=False)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(con._loss.item())
+
+    # ---- roofline of the dominant kernel (the fused forward/backward), HIP events on the launch stream
+    dev, n_pos = con.sample_device()
+    torch.cuda.synchronize()
+    start = [torch.cuda.Event(enable_timing=True) for _ in range(args.kernel_reps)]
+    stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.kernel_reps)]
+    for i in range(args.kernel_reps):
+        start[i].record()
+        con.forward_backward(dev, n_pos, max(n_local, 1), B * NEG)
+        stop[i].record()
+    torch.cuda.synchronize()
+    for g in con._grads:
+        g.zero_()
+    kern_ms = sorted(s.elapsed_time(e) for s, e in zip(start, stop))
+    kern_ms = sum(kern_ms) / len(kern_ms)
+    alg_bytes = algorithmic_bytes_per_positive(NEG, DIM) * n_pos
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tr_path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr_path):
+        try:
+            traffic = json.load(open(tr_path)).get("fwdbwd_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "positive triples/sec (training step)",
+            "value": B * args.steps / dt,
+            "unit": "positive triples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "FB15k-237-shaped synthetic KG (E=14541,R=237,272115 triples), TransE dim=200, "
+                                   "TF1-semantics Adam, 25 neg/pos bern, margin 1.0 (BASELINE configs[1], fp32)",
+                       "global_batch": B, "per_gpu_batch": n_local, "neg_per_pos": NEG, "dim": DIM,
+                       "optimizer": "Adam(dense, TF1 parity)", "work_threads": WORK_THREADS,
+                       "parallelism": "dp%d" % world, "final_loss": loss},
+            "roofline": {"bound": "hbm", "kernel": "kge::fwdbwd_kernel<TransE,64,4> (+loss_finalize)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(fb_dir)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
