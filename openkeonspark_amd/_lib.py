@@ -63,6 +63,13 @@ def _declare(L):
 def load(path=None):
     """Load the engine library.  Raises ImportError when it has not been built."""
     path = path or LIB_PATH
+    try:
+        # PyTorch (the host plumbing: device memory, streams, torch.distributed) bundles its own HIP
+        # runtime; it must be the one already resident when the engine's libamdhip64 dependency is
+        # resolved, or the process ends up with two runtimes and the engine sees no device.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise ImportError(
             "%s not found: build it first (python -c 'import __graft_entry__ as g; g.build()' or "

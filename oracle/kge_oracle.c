@@ -423,11 +423,19 @@ typedef struct {
     int width[4];
     float lr;
     int immediate;
+    int atomic;       /* several threads share the accumulators */
 } Sink;
 
 static inline void emit(Sink *K, int tab, i64 row, const float *v) {
     int w = K->width[tab];
     if (K->immediate) { float *p = K->p[tab] + row * w; for (int i = 0; i < w; i++) p[i] -= v[i] * K->lr; }
+    else if (K->atomic) {
+        float *g = K->g[tab] + row * w;
+        for (int i = 0; i < w; i++) {
+#pragma omp atomic
+            g[i] += v[i];
+        }
+    }
     else { float *g = K->g[tab] + row * w; for (int i = 0; i < w; i++) g[i] += v[i]; }
 }
 
@@ -533,32 +541,26 @@ float orc_loss(const OrcModel *M, const i64 *bh, const i64 *bt, const i64 *br, i
 /* Dense gradients of the loss w.r.t. every table (the dedup-summed IndexedSlices).  grads[i] must
  * be zero-initialised arrays of the table shapes (NULL for absent tables).  B_total/N_total allow a
  * data-parallel shard to be differentiated with the global mean's denominator.
- * Thread t handles a contiguous block of positives into a private accumulator; accumulators are
- * added in thread order, so nthreads=1 is the plain sequential sum. */
+ * With nthreads > 1 the threads split the positives and add into the shared accumulators with
+ * atomic float adds (summation order then varies in the last bits); nthreads = 1 is the plain
+ * sequential sum. */
 float orc_grad(const OrcModel *M, const i64 *bh, const i64 *bt, const i64 *br, i64 B, i64 N,
                i64 denom, float *grads[4], int nthreads) {
     float *ps = malloc(sizeof(float) * (size_t)B), *ns = malloc(sizeof(float) * (size_t)(B * N));
+    if (nthreads < 1) nthreads = 1;
     float loss = forward_all(M, bh, bt, br, B, N, ps, ns, nthreads);
     if (denom != B * N) loss = loss * (float)(B * N) / (float)denom;
     float unit = 1.0f / (float)denom;
     i64 rows[4]; int width[4];
     table_shapes(M, rows, width);
-    if (nthreads < 1) nthreads = 1;
-    float **priv = calloc((size_t)nthreads * 4, sizeof(float *));
-    for (int th = 0; th < nthreads; th++)
-        for (int i = 0; i < 4; i++)
-            priv[th * 4 + i] = (th == 0) ? grads[i] : (rows[i] ? calloc((size_t)(rows[i] * width[i]), sizeof(float)) : NULL);
 #pragma omp parallel num_threads(nthreads)
     {
-        int th = 0;
-#ifdef _OPENMP
-        th = omp_get_thread_num();
-#endif
         Sink K; memset(&K, 0, sizeof K);
-        for (int i = 0; i < 4; i++) { K.g[i] = priv[th * 4 + i]; K.width[i] = width[i]; }
+        for (int i = 0; i < 4; i++) { K.g[i] = grads[i]; K.width[i] = width[i]; }
+        K.atomic = nthreads > 1;
         Scratch *S = malloc(sizeof(Scratch));
-        i64 lo = B * th / nthreads, hi = B * (th + 1) / nthreads;
-        for (i64 b = lo; b < hi; b++) {
+#pragma omp for schedule(static)
+        for (i64 b = 0; b < B; b++) {
             /* d loss / d p_b = (#active negatives)/denom ; d loss / d n_bk = -[active]/denom.
              * TF maximum(x,0) routes the gradient to x when x >= 0. */
             float gp = 0.f;
@@ -577,15 +579,7 @@ float orc_grad(const OrcModel *M, const i64 *bh, const i64 *bt, const i64 *br, i
         }
         free(S);
     }
-    for (int th = 1; th < nthreads; th++)
-        for (int i = 0; i < 4; i++) {
-            if (!rows[i]) continue;
-            float *a = grads[i], *bsrc = priv[th * 4 + i];
-            i64 n = rows[i] * width[i];
-            for (i64 q = 0; q < n; q++) a[q] += bsrc[q];
-            free(bsrc);
-        }
-    free(priv); free(ps); free(ns);
+    free(ps); free(ns);
     return loss;
 }
 
@@ -631,6 +625,7 @@ float orc_sgd_step_sequential(OrcModel *M, const i64 *bh, const i64 *bt, const i
 /* SGD with the duplicate slices summed first: p -= lr * G.  Same mathematics as above, different
  * rounding order; this is the order the HIP engine uses. */
 void orc_sgd_apply_dense(float *p, const float *g, i64 n, float lr) {
+#pragma omp parallel for schedule(static) if (n > 100000)
     for (i64 i = 0; i < n; i++) p[i] -= lr * g[i];
 }
 
@@ -641,6 +636,7 @@ void orc_sgd_apply_dense(float *p, const float *g, i64 n, float lr) {
 void orc_adam_apply_dense(float *p, float *m, float *v, const float *g, i64 n,
                           float lr_t, float beta1, float beta2, float eps) {
     float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+#pragma omp parallel for schedule(static) if (n > 100000)
     for (i64 i = 0; i < n; i++) {
         float mi = m[i] * beta1;
         float vi = v[i] * beta2;
