@@ -39,12 +39,29 @@ def algorithmic_bytes_per_positive(n_neg, dim, elem=4):
     return 2 * u * dim * elem + 12 * (1 + n_neg)
 
 
+def usable_cpus(omp_max):
+    """CPUs this job may actually use: the smaller of OpenMP's count, the affinity mask and the cgroup
+    quota (a 1-GPU box grants a share of the host, and oversubscribing it only measures contention)."""
+    n = omp_max
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("KGE_CPU_BASELINE_THREADS", "64"))))
+
+
 def cpu_baseline(fb_dir, seconds=12.0):
     """The CPU oracle (C restatement of the reference path: sampler + TransE fwd/bwd + TF1 Adam) timed
     on this host, all cores for the model part, on a bounded sample of the same workload."""
     import numpy as np
     from oracle import oracle
-    threads = oracle.lib().orc_max_threads()
+    threads = usable_cpus(oracle.lib().orc_max_threads())
     kg = oracle.KG(fb_dir, work_threads=WORK_THREADS, bern=1)
     B = 4096
     m = oracle.Model("transe", kg.entTotal, kg.relTotal, DIM, margin=1.0, seed=0)
