@@ -59,6 +59,25 @@ int hip_check(hipError_t e, const char *what);
 
 constexpr int kMaxLossBlocks = 4096;
 
+// How a negative relates to its positive.  A slot is "same" when the vector the score uses for it is
+// the positive's: same entity AND same projection context (TransH/D: same relation; TransR: same
+// matrix, which is the positive's whenever negative_rel == 0, TransR.py:57-60; TransE: no context).
+// fast = exactly one of the three vectors differs -> the other two stay in registers.
+struct NegClass { bool same_h, same_t, same_r, fast; };
+template <int MODEL>
+__host__ __device__ inline NegClass classify_negative(long long h, long long t, long long r, long long nh,
+                                                               long long nt, long long nr, int negative_rel) {
+    NegClass c;
+    c.same_r = nr == r;
+    const bool ctx_same = MODEL == KGE_TRANSE ? true : (MODEL == KGE_TRANSR ? (negative_rel == 0 || c.same_r) : c.same_r);
+    c.same_h = nh == h && ctx_same;
+    c.same_t = nt == t && ctx_same;
+    c.fast = ((int)!c.same_h + (int)!c.same_t + (int)!c.same_r) == 1;
+    return c;
+}
+
+
+
 // ---- launchers implemented in the .hip files ------------------------------------------------
 int launch_sampler(int32_t *d_h, int32_t *d_t, int32_t *d_r, int64_t B, int64_t neg, int64_t negrel, int64_t thread_lo,
                    int64_t thread_hi, int64_t out_stride, int64_t *n_local, hipStream_t stream);

@@ -59,6 +59,11 @@ struct FbArgs {
     int D;
     float margin, unit;
     float *loss_partials;
+    // TransR vector stage (transr.hip): entity sides are rows of the projected buffer P (one row per
+    // canonical (scored triple, side) slot) and their gradients are STORED to GP, not added to g_ent
+    const float *P;
+    float *GP;
+    int negative_rel;
 };
 
 template <int L, int C>
@@ -77,6 +82,11 @@ struct Team {
             int e = lane + L * c;
             if (e < D) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(p + e), v[c]);
         }
+    }
+    __device__ __forceinline__ void store(float *__restrict__ tab, long long row, const float (&v)[C]) const {
+        float *p = tab + row * D;
+#pragma unroll
+        for (int c = 0; c < C; c++) { int e = lane + L * c; if (e < D) p[e] = v[c]; }
     }
     __device__ __forceinline__ float dot(const float (&a)[C], const float (&b)[C]) const {
         float s = 0.f;
@@ -116,9 +126,10 @@ struct Side {
 template <int MODEL, int L, int C>
 __device__ __forceinline__ void side_forward(const Team<L, C> &tm, const FbArgs &a, long long row, const float (&cw)[C],
                                              Side<C> &s) {
-    tm.load(a.ent, row, s.raw);
+    if constexpr (MODEL == KGE_TRANSR) tm.load(a.P, row, s.raw);  // row = slot of the projected buffer
+    else tm.load(a.ent, row, s.raw);
     float xp[C];
-    if constexpr (MODEL == KGE_TRANSE) {
+    if constexpr (MODEL == KGE_TRANSE || MODEL == KGE_TRANSR) {
 #pragma unroll
         for (int c = 0; c < C; c++) xp[c] = s.raw[c];
         s.a = 0.f;
@@ -144,6 +155,8 @@ __device__ __forceinline__ void side_backward(const Team<L, C> &tm, const FbArgs
     tm.normalize_bwd(s.nrm, G, s.inv, s.uc, gxp);
     if constexpr (MODEL == KGE_TRANSE) {
         tm.add(a.g_ent, row, gxp);
+    } else if constexpr (MODEL == KGE_TRANSR) {
+        tm.store(a.GP, row, gxp);  // each canonical slot is written by exactly one team
     } else if constexpr (MODEL == KGE_TRANSH) {
         float d = tm.dot(gxp, cw);
         float gx[C];
@@ -217,6 +230,7 @@ __device__ __forceinline__ float l1_score(const Team<L, C> &tm, const float (&hn
 template <int MODEL, int L, int C>
 __device__ __forceinline__ bool standalone_negative(const Team<L, C> &tm, const FbArgs &a, long long nh, long long nt,
                                                     long long nr, float p, float &hinge) {
+    // nh / nt are ROW HANDLES (entity ids, or projected-buffer slots for TransR); nr the relation id
     Ctx<C> cx;
     ctx_forward<MODEL, L, C>(tm, a, nr, cx);
     float sg[C];
@@ -269,9 +283,13 @@ __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
         const long long h = a.bh[b], t = a.bt[b], r = a.br[b];
         Ctx<C> cx;
         ctx_forward<MODEL, L, C>(tm, a, r, cx);
+        // row handles of the two entity sides: the entity id, or (TransR) the slot of the projected
+        // vector of (scored triple s, side): 2*s + side with s = k*n_pos + b
+        const long long row_h = MODEL == KGE_TRANSR ? 2 * b : h;
+        const long long row_t = MODEL == KGE_TRANSR ? 2 * b + 1 : t;
         Side<C> sh, st;
-        side_forward<MODEL, L, C>(tm, a, h, cx.cw, sh);
-        side_forward<MODEL, L, C>(tm, a, t, cx.cw, st);
+        side_forward<MODEL, L, C>(tm, a, row_h, cx.cw, sh);
+        side_forward<MODEL, L, C>(tm, a, row_t, cx.cw, st);
         float sp[C];
         const float p = l1_score<L, C>(tm, sh.nrm, cx.rn, st.nrm, sp);
         // gradients w.r.t. the three shared normalised vectors, in units of `unit`
@@ -282,18 +300,19 @@ __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
         for (long long k = 0; k < a.n_neg; k++) {
             const long long j = b + (k + 1) * a.stride;
             const long long nh = a.bh[j], nt = a.bt[j], nr = a.br[j];
-            const bool same_r = nr == r;
-            const int ndiff = (nh != h) + (nt != t) + (nr != r);
-            const bool fast = ndiff == 1 && (same_r || MODEL == KGE_TRANSE);
-            if (!fast) {
+            const NegClass nc = classify_negative<MODEL>(h, t, r, nh, nt, nr, a.negative_rel);
+            const long long s_neg = (k + 1) * a.n_pos + b;
+            const long long nrow_h = MODEL == KGE_TRANSR ? 2 * s_neg : nh;
+            const long long nrow_t = MODEL == KGE_TRANSR ? 2 * s_neg + 1 : nt;
+            if (!nc.fast) {
                 float hinge;
-                if (standalone_negative<MODEL, L, C>(tm, a, nh, nt, nr, p, hinge)) { cnt++; lsum += hinge; }
+                if (standalone_negative<MODEL, L, C>(tm, a, nrow_h, nrow_t, nr, p, hinge)) { cnt++; lsum += hinge; }
                 continue;
             }
             float sg[C];
-            if (nh != h) {  // head corrupted (corrupt_tail keeps t, Base.cpp:123-126)
+            if (!nc.same_h) {  // head corrupted (corrupt_tail keeps t, Base.cpp:123-126)
                 Side<C> sx;
-                side_forward<MODEL, L, C>(tm, a, nh, cx.cw, sx);
+                side_forward<MODEL, L, C>(tm, a, nrow_h, cx.cw, sx);
                 float nk = l1_score<L, C>(tm, sx.nrm, cx.rn, st.nrm, sg);
                 float v = p - nk + a.margin;
                 if (v >= 0.f) {
@@ -301,11 +320,11 @@ __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
                     float G[C];
 #pragma unroll
                     for (int c = 0; c < C; c++) { G[c] = -a.unit * sg[c]; At[c] += sg[c]; Ar[c] -= sg[c]; }
-                    side_backward<MODEL, L, C>(tm, a, nh, sx, G, cx.cw, acw);
+                    side_backward<MODEL, L, C>(tm, a, nrow_h, sx, G, cx.cw, acw);
                 }
-            } else if (nt != t) {  // tail corrupted (corrupt_head keeps h, Base.cpp:119-121)
+            } else if (!nc.same_t) {  // tail corrupted (corrupt_head keeps h, Base.cpp:119-121)
                 Side<C> sx;
-                side_forward<MODEL, L, C>(tm, a, nt, cx.cw, sx);
+                side_forward<MODEL, L, C>(tm, a, nrow_t, cx.cw, sx);
                 float nk = l1_score<L, C>(tm, sh.nrm, cx.rn, sx.nrm, sg);
                 float v = p - nk + a.margin;
                 if (v >= 0.f) {
@@ -313,9 +332,9 @@ __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
                     float G[C];
 #pragma unroll
                     for (int c = 0; c < C; c++) { G[c] = a.unit * sg[c]; Ah[c] -= sg[c]; Ar[c] -= sg[c]; }
-                    side_backward<MODEL, L, C>(tm, a, nt, sx, G, cx.cw, acw);
+                    side_backward<MODEL, L, C>(tm, a, nrow_t, sx, G, cx.cw, acw);
                 }
-            } else {  // relation corrupted, TransE only (no projection depends on r)
+            } else {  // relation vector corrupted while both projected entities are shared (TransE; TransR with negative_rel == 0)
                 float raw[C], xn[C], inv; bool uc;
                 tm.load(a.rel, nr, raw);
                 tm.normalize(raw, xn, inv, uc);
@@ -340,8 +359,8 @@ __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
                 Gt[c] = a.unit * (At[c] - fc * sp[c]);
                 Gr[c] = a.unit * (Ar[c] + fc * sp[c]);
             }
-            side_backward<MODEL, L, C>(tm, a, h, sh, Gh, cx.cw, acw);
-            side_backward<MODEL, L, C>(tm, a, t, st, Gt, cx.cw, acw);
+            side_backward<MODEL, L, C>(tm, a, row_h, sh, Gh, cx.cw, acw);
+            side_backward<MODEL, L, C>(tm, a, row_t, st, Gt, cx.cw, acw);
             ctx_backward<MODEL, L, C>(tm, a, r, cx, Gr, acw);
         }
     }
@@ -393,6 +412,24 @@ static int dispatch_fb(const FbArgs &a, float *d_loss, hipStream_t stream) {
     return KGE_OK;
 }
 
+// TransR: the score / hinge / backward over the projected vectors (transr.hip runs the GEMMs around it)
+int launch_transr_vector_stage(const float *rel, float *g_rel, const float *P, float *GP, const int32_t *d_h,
+                               const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
+                               int64_t denom, int rel_dim, float margin, int negative_rel, float *d_loss,
+                               hipStream_t stream) {
+    Engine &e = engine();
+    FbArgs a = {};
+    a.rel = rel; a.g_rel = g_rel; a.P = P; a.GP = GP;
+    a.bh = d_h; a.bt = d_t; a.br = d_r;
+    a.n_pos = n_pos; a.n_neg = n_neg; a.stride = stride;
+    a.D = rel_dim; a.margin = margin; a.unit = 1.0f / (float)denom;
+    a.loss_partials = e.dev.loss_partials;
+    a.negative_rel = negative_rel;
+    int rc = dispatch_fb<KGE_TRANSR>(a, d_loss, stream);
+    if (rc) return rc;
+    return hip_check(hipGetLastError(), "transr vector stage launch");
+}
+
 int launch_forward_backward_transr(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h,
                                    const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
                                    int64_t denom, float *const grads[4], float *d_loss, hipStream_t stream);
@@ -417,6 +454,7 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
     a.n_pos = n_pos; a.n_neg = n_neg; a.stride = stride;
     a.D = m.ent_dim; a.margin = m.margin; a.unit = 1.0f / (float)denom;
     a.loss_partials = e.dev.loss_partials;
+    a.P = nullptr; a.GP = nullptr; a.negative_rel = m.negative_rel;
     int rc;
     switch (m.model) {
         case KGE_TRANSE: rc = dispatch_fb<KGE_TRANSE>(a, d_loss, stream); break;
@@ -442,8 +480,8 @@ __global__ __launch_bounds__(256) void predict_kernel(FbArgs a, long long n, flo
         Ctx<C> cx;
         ctx_forward<MODEL, L, C>(tm, a, a.br[i], cx);
         Side<C> sh, st;
-        side_forward<MODEL, L, C>(tm, a, a.bh[i], cx.cw, sh);
-        side_forward<MODEL, L, C>(tm, a, a.bt[i], cx.cw, st);
+        side_forward<MODEL, L, C>(tm, a, MODEL == KGE_TRANSR ? 2 * i : (long long)a.bh[i], cx.cw, sh);
+        side_forward<MODEL, L, C>(tm, a, MODEL == KGE_TRANSR ? 2 * i + 1 : (long long)a.bt[i], cx.cw, st);
         float sg[C];
         float s = l1_score<L, C>(tm, sh.nrm, cx.rn, st.nrm, sg);
         if (tm.lane == 0) out[i] = MODEL == KGE_TRANSE ? s / (float)a.D : s;
@@ -474,6 +512,16 @@ static int dispatch_predict(const FbArgs &a, long long n, float *out, hipStream_
 
 int launch_predict_transr(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
                           const int32_t *d_r, int64_t n, float *d_out, hipStream_t stream);
+
+// TransR predict: sum |l2n(P[2i]) + l2n(rel[r_i]) - l2n(P[2i+1])| over the projected vectors (TransR.py:77-87)
+int launch_transr_predict_stage(const float *rel, const float *P, const int32_t *d_r, int64_t n, int rel_dim, float *d_out,
+                                hipStream_t stream) {
+    FbArgs a = {};
+    a.rel = rel; a.P = P; a.br = d_r; a.D = rel_dim;
+    int rc = dispatch_predict<KGE_TRANSR>(a, n, d_out, stream);
+    if (rc) return rc;
+    return hip_check(hipGetLastError(), "transr predict launch");
+}
 
 int launch_predict(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
                    const int32_t *d_r, int64_t n, float *d_out, hipStream_t stream) {

@@ -63,6 +63,32 @@ CASES = [("transe", 300, 11, 16), ("transe", 300, 11, 100), ("transe", 200, 7, 2
          ("transh", 300, 11, 24), ("transh", 200, 7, 200), ("transh", 64, 5, 100),
          ("transd", 300, 11, 20), ("transd", 200, 7, 200), ("transd", 64, 5, 100)]
 
+TRANSR_CASES = [(120, 9, 12, 8), (150, 7, 200, 200), (90, 5, 64, 100), (60, 4, 33, 50)]
+
+
+@pytest.mark.parametrize("E,R,De,Dr", TRANSR_CASES)
+@pytest.mark.parametrize("n,nr,foreign", [(1, 0, 0.0), (5, 0, 0.0), (2, 1, 0.0), (3, 1, 0.3), (4, 0, 0.3)])
+def test_transr_forward_backward_matches_oracle(E, R, De, Dr, n, nr, foreign):
+    """Relation-bucketed fp32-MFMA TransR (projection, dgrad, wgrad) against the oracle."""
+    import torch
+    rng = np.random.default_rng(abs(hash((De, Dr, n, nr))) % 2**32)
+    B = 301
+    params = oracle.init_params(oracle.TRANSR, E, R, De, Dr, seed=4)
+    for k in params:
+        params[k] = (params[k] * 3).astype(np.float32)
+    bh, bt, br = rand_batch(rng, E, R, B, n, nr, foreign)
+    orc = oracle.Model("transr", E, R, De, Dr, margin=0.9, negative_rel=nr, params=params)
+    loss_o, g_o = orc.grad(bh, bt, br, B, n + nr)
+    con = make_engine("transr", E, R, De, n, nr, margin=0.9, params=params, Dr=Dr)
+    dev = torch.from_numpy(np.stack([bh, bt, br]).astype(np.int32)).cuda()
+    con.forward_backward(dev, B, B, B * (n + nr))
+    torch.cuda.synchronize()
+    loss_g = float(con._loss.item())
+    g_g = con.get_gradients()
+    assert abs(loss_g - loss_o) <= RTOL * abs(loss_o), (loss_g, loss_o)
+    for k in g_o:
+        assert relerr(g_g[k], g_o[k]) < RTOL, (k, relerr(g_g[k], g_o[k]))
+
 
 @pytest.mark.parametrize("model,E,R,D", CASES)
 @pytest.mark.parametrize("n,nr,foreign", [(1, 0, 0.0), (5, 0, 0.0), (2, 1, 0.0), (3, 1, 0.3)])
@@ -87,7 +113,7 @@ def test_forward_backward_matches_oracle(model, E, R, D, n, nr, foreign):
         assert relerr(g_g[k], g_o[k]) < RTOL, (k, relerr(g_g[k], g_o[k]))
 
 
-@pytest.mark.parametrize("model", ["transe", "transh", "transd"])
+@pytest.mark.parametrize("model", ["transe", "transh", "transd", "transr"])
 @pytest.mark.parametrize("opt", ["SGD", "Adam"])
 def test_training_steps_match_oracle(model, opt):
     """Several optimiser steps on fed batches: parameters, Adam slots and losses track the oracle."""
@@ -162,7 +188,7 @@ def test_sampled_training_matches_oracle_end_to_end(fb_dir):
     assert con.get_stream_states().tolist() == kg.stream_states().tolist()
 
 
-@pytest.mark.parametrize("model", ["transe", "transh", "transd"])
+@pytest.mark.parametrize("model", ["transe", "transh", "transd", "transr"])
 def test_predict_matches_oracle(model):
     rng = np.random.default_rng(3)
     E, R, D = 90, 4, 100
@@ -170,6 +196,8 @@ def test_predict_matches_oracle(model):
     con = make_engine(model, E, R, D, 1, 0, params=params)
     orc = oracle.Model(model, E, R, D, D, params=params)
     h = rng.integers(0, E, 333); t = rng.integers(0, E, 333); r = rng.integers(0, R, 333)
+    if model == "transr":
+        r[0] = 2  # TransR.py:83: every triple is projected with predict_r[0]'s matrix
     got = con.test_step(h, t, r)
     want = orc.predict(h, t, r)
     assert np.allclose(got, want, rtol=1e-5, atol=0)
