@@ -13,7 +13,7 @@
 //   project   P[slot]  = ent[e] . M_r                      MFMA, 32 x 128 output tile per workgroup
 //   vector    models.hip fwdbwd_kernel<TRANSR>: normalise, L1 score, hinge, backward -> GP[slot], g_rel
 //   dgrad     g_ent[e] += GP[slot] . M_r^T                 MFMA + fp32 atomics (rows of `de` floats)
-//   wgrad     g_M[r]   += X_r^T . GP_r  over the bucket    MFMA, one owner per (r, tile): no atomics
+//   wgrad     g_M[r]   += X_r^T . GP_r  over the bucket    MFMA, buckets split over workgroups, fp32 atomics
 //
 // FLOPs per scored triple: fwd 2 projections 4.de.dr, bwd 8.de.dr.
 #include <cstring>
@@ -242,22 +242,51 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(GemmArgs a) {
     }
 }
 
-// g_M[r][i][j] += sum over the bucket's rows of ent[e_row][i] * GP[slot_row][j]
+// g_M[r][i][j] += sum over the bucket's rows of ent[e_row][i] * GP[slot_row][j].
+// Work unit = WG_TILES consecutive 32-row tiles of the (relation-sorted) job list, so a hub relation's
+// bucket is split over many workgroups; a workgroup flushes its 32 x 128 partial with fp32 atomics
+// whenever the relation changes inside its span (Zipf-skewed relations: one bucket can hold 15% of
+// the batch, a single owner per relation would serialise on it).
+constexpr int WG_TILES = 8;
+
+__device__ __forceinline__ void wgrad_flush(const GemmArgs &a, float *__restrict__ g_mat, int r, int i0, int jg, int lane,
+                                            const f32x16 &acc) {
+    if (jg >= a.Dr) return;
+    float *G = g_mat + (long long)r * a.De * a.Dr;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        const int ig = i0 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (ig < a.De)
+            __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(G + (long long)ig * a.Dr + jg), acc[reg]);
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_kernel(GemmArgs a, float *__restrict__ g_mat, int tiles_i) {
-    const int r = blockIdx.x / tiles_i, it = blockIdx.x - r * tiles_i;
-    const int start = a.bucket_start[r], end = a.bucket_start[r + 1];
-    if (start >= end) return;
+    const int grp = blockIdx.x / tiles_i, it = blockIdx.x - grp * tiles_i;
+    const int n_tiles = a.n_tiles[0];
+    const int t0 = grp * WG_TILES;
+    if (t0 >= n_tiles) return;
+    const int t1 = min(t0 + WG_TILES, n_tiles);
     __shared__ float As[KC][32 + 1];
     __shared__ float Bs[KC][TN + 1];
     __shared__ int s_slot[KC], s_ent[KC];
     const int i0 = it * 32, j0 = blockIdx.y * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jg = j0 + wave * 32 + (lane & 31);
     f32x16 acc = {0};
-    for (int c0 = start; c0 < end; c0 += KC) {
-        const int rows = min(KC, end - c0);
+    int r_cur = a.tile_rel[t0];
+    for (int t = t0; t < t1; t++) {
+        const int r = a.tile_rel[t];
+        if (r != r_cur) {
+            wgrad_flush(a, g_mat, r_cur, i0, jg, lane, acc);
+            acc = f32x16{0};
+            r_cur = r;
+        }
+        const int row0 = a.tile_row0[t];
+        const int rows = min(32, a.bucket_start[r + 1] - row0);
         __syncthreads();
         if (tid < KC) {
-            int sl = tid < rows ? a.sorted_slots[c0 + tid] : -1;
+            int sl = tid < rows ? a.sorted_slots[row0 + tid] : -1;
             s_slot[tid] = sl;
             s_ent[tid] = sl >= 0 ? a.job_ent[sl] : -1;
         }
@@ -278,15 +307,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(GemmArgs a, float *__restric
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
     }
-    const int jg = j0 + wave * 32 + (lane & 31);
-    if (jg < a.Dr) {
-        float *G = g_mat + (long long)r * a.De * a.Dr;
-#pragma unroll
-        for (int reg = 0; reg < 16; reg++) {
-            const int ig = i0 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            if (ig < a.De) G[(long long)ig * a.Dr + jg] += acc[reg];  // single owner of (r, tile): no atomics
-        }
-    }
+    wgrad_flush(a, g_mat, r_cur, i0, jg, lane, acc);
 }
 
 int bits_for(int64_t v) { int b = 1; while ((int64_t(1) << b) <= v) b++; return b; }
@@ -328,7 +349,8 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     if (rc) return rc;
     hipLaunchKernelGGL((rows_gemm_kernel<GEMM_DGRAD>), dim3(max_tiles, (De + TN - 1) / TN), dim3(256), 0, stream, ga);
     const int tiles_i = (De + 31) / 32;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(R * tiles_i), (Dr + TN - 1) / TN), dim3(256), 0, stream, ga, grads[2], tiles_i);
+    const unsigned groups = (max_tiles + WG_TILES - 1) / WG_TILES;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(groups * tiles_i, (Dr + TN - 1) / TN), dim3(256), 0, stream, ga, grads[2], tiles_i);
     return hip_check(hipGetLastError(), "transr launch");
 }
 
