@@ -82,6 +82,10 @@ void kge_clear_error(void);
 int kge_device_available(void);
 const char *kge_version(void);
 
+/* engine options (testing / tuning).  "counts_force_sort": 1 = always reduce sign-count records with
+ * the sort + segmented-sum kernels, 0 (default) = use the LDS-bucket reduction when the table fits */
+int kge_set_option(const char *name, INT value);
+
 /* Same as importTrainFiles but from arrays already in memory (h,t,r in FILE ORDER, duplicates
  * kept; new_batch_total as batch2id.txt's first line, 0 = not incremental).  Restates
  * Reader.h:82-177 without the text parse. */
@@ -155,6 +159,25 @@ int kge_sgd_update(float *d_p, float *d_g, int64_t n, float lr, void *stream);
  * row decays and moves.  lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) computed by the caller; g = 0 after. */
 int kge_adam_update(float *d_p, float *d_m, float *d_v, float *d_g, int64_t n, float lr_t, float beta1,
                     float beta2, float eps, void *stream);
+
+/* ---- TransE sign-count path (exact integer gradients, no fp32 atomics) ----------------------
+ * For the L1 score of TransE.py:11-15 the gradient w.r.t. every l2-normalised vector is (1/denom) x an
+ * integer vector of signs, so the backward can be carried as exact int32 COUNTS per table row:
+ *   counts[(E+R), D]  rows [0,E) = ent_embeddings, rows [E,E+R) = rel_embeddings.
+ * kge_transe_forward_counts = gather/score/hinge (as kge_forward_backward) + int8 gradient records +
+ * sort-and-sum into `d_counts` (must be zero on entry; kge_transe_apply_counts re-zeroes it).  The
+ * counts are order-independent, so a data-parallel all-reduce of them is exact and every replica
+ * stays bit-identical.  Negatives that are not sampler-shaped (more than one slot differs from the
+ * positive) are differentiated exactly in fp32 into the residual accumulators d_resid_ent [E,D] /
+ * d_resid_rel [R,D] (zero on entry, all-zero afterwards for sampler batches).
+ * kge_transe_apply_counts: per row g = (1/denom)*inv*(S - x^<x^,S>) + resid (the normalise-backward
+ * applied once to the summed counts), then SGD (adam=0, lr) or TF1 Adam (adam=1, lr = lr_t) in place. */
+int kge_transe_counts_supported(const kge_model_desc *m, INT n_neg);
+int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const float *d_rel, const int32_t *d_h,
+                              const int32_t *d_t, const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom,
+                              int32_t *d_counts, float *d_resid_ent, float *d_resid_rel, float *d_loss, void *stream);
+int kge_transe_apply_counts(float *d_p, float *d_m, float *d_v, int32_t *d_counts, float *d_resid, int64_t rows, int32_t dim,
+                            INT denom, int32_t adam, float lr, float beta1, float beta2, float eps, void *stream);
 
 /* predict op: score n triples.  TransE: mean over the dimension (TransE.py:58); others: sum
  * (TransH.py:82, TransR.py:87 with predict_r[0]'s matrix for all, TransD.py:98). */

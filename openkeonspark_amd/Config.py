@@ -248,6 +248,13 @@ class Config(object):
         self._grad_ptrs = _lib.table_ptrs([g.data_ptr() for g in self._grads])
         self._dev_batch = None
         self.global_step = 0
+        # TransE: exact integer sign-count gradients instead of fp32 atomics (include/kge_mi355.h)
+        n_neg = self.negative_ent + self.negative_rel
+        self.use_counts = bool(getattr(self, "use_counts", True)) and bool(
+            self.lib.kge_transe_counts_supported(ctypes.byref(self._desc), n_neg))
+        if self.use_counts:
+            self._counts = torch.zeros((self.entTotal + self.relTotal, self.hidden_size), dtype=torch.int32,
+                                       device=self.device)
         self._setup_partition()
 
     # --- data-parallel partition: rank g owns virtual threads [g*W/G, (g+1)*W/G) ---
@@ -335,13 +342,50 @@ class Config(object):
             dev = torch.from_numpy(host).to(self.device)
             n_pos = host.shape[1] // (1 + n_neg)
             stride = n_pos
-        self.forward_backward(dev, n_pos, stride, self.batch_size * n_neg if batch_h is None else n_pos * n_neg)
-        if self.world_size > 1:
-            from .parallel import allreduce_gradients
-            allreduce_gradients(self._grads + [self._loss], self._pg)
-        self.apply_gradients()
+        denom = self.batch_size * n_neg if batch_h is None else n_pos * n_neg
+        if self.use_counts:
+            self.forward_counts(dev, n_pos, stride, denom)
+            if self.world_size > 1:
+                from .parallel import allreduce_gradients
+                allreduce_gradients([self._counts, self._loss], self._pg)  # int32 SUM: exact
+            self.apply_counts(denom)
+        else:
+            self.forward_backward(dev, n_pos, stride, denom)
+            if self.world_size > 1:
+                from .parallel import allreduce_gradients
+                allreduce_gradients(self._grads + [self._loss], self._pg)
+            self.apply_gradients()
         self.trainModel.loss = self._loss
         return float(self._loss.item()) if sync else self._loss
+
+    def forward_counts(self, dev_batch, n_pos, stride, denom):
+        """TransE sign-count forward/backward: exact int32 gradient counts -> self._counts."""
+        _lib.check(self.lib.kge_transe_forward_counts(
+            ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(),
+            dev_batch[0].data_ptr(), dev_batch[1].data_ptr(), dev_batch[2].data_ptr(), n_pos,
+            self.negative_ent + self.negative_rel, stride, denom, self._counts.data_ptr(),
+            self._grads[0].data_ptr(), self._grads[1].data_ptr(), self._loss.data_ptr(), self._stream()), self.lib)
+
+    def apply_counts(self, denom):
+        """Normalise-backward on the summed counts + SGD / TF1 Adam, per table (distribute_training.py:95-101)."""
+        st = self._stream()
+        f = np.float32
+        if self._adam:
+            lr = float(f(f(self.alpha) * np.sqrt(f(1) - self._beta2_power, dtype=np.float32) / (f(1) - self._beta1_power)))
+        else:
+            lr = float(self.alpha)
+        D = self.hidden_size
+        for i, (row0, rows) in enumerate(((0, self.entTotal), (self.entTotal, self.relTotal))):
+            m = self._adam_m[i].data_ptr() if self._adam else None
+            v = self._adam_v[i].data_ptr() if self._adam else None
+            _lib.check(self.lib.kge_transe_apply_counts(
+                self._tables[i].data_ptr(), m, v, self._counts.data_ptr() + row0 * D * 4, self._grads[i].data_ptr(),
+                rows, D, denom, 1 if self._adam else 0, lr, self.adam_beta1, self.adam_beta2, self.adam_epsilon, st),
+                self.lib)
+        if self._adam:
+            self._beta1_power = f(self._beta1_power * f(self.adam_beta1))
+            self._beta2_power = f(self._beta2_power * f(self.adam_beta2))
+        self.global_step += 1
 
     def test_step(self, test_h, test_t, test_r):
         '''

@@ -44,6 +44,7 @@ def _declare(L):
     L.kge_device_available.restype = ctypes.c_int
     L.kge_version.restype = ctypes.c_char_p
     L.kge_import_train_arrays.argtypes = [i64, i64, i64, vp, vp, vp, i64]
+    L.kge_set_option.argtypes = [ctypes.c_char_p, i64]
     L.kge_index_copy.restype = i64
     L.kge_index_copy.argtypes = [ctypes.c_char_p, vp, i64]
     L.kge_get_stream_states.argtypes = [vp, i64]
@@ -57,6 +58,9 @@ def _declare(L):
     L.kge_sgd_update.argtypes = [vp, vp, i64, f32, vp]
     L.kge_adam_update.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp]
     L.kge_predict.argtypes = [ctypes.POINTER(ModelDesc), tabs, vp, vp, vp, i64, vp, vp]
+    L.kge_transe_counts_supported.argtypes = [ctypes.POINTER(ModelDesc), i64]
+    L.kge_transe_forward_counts.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp]
+    L.kge_transe_apply_counts.argtypes = [vp, vp, vp, vp, vp, i64, i32, i64, i32, f32, f32, f32, f32, vp]
     return L
 
 

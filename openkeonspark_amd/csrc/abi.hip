@@ -197,6 +197,12 @@ void kge_clear_error(void) { engine().last_error.clear(); }
 int kge_device_available(void) { return device_ok() ? 1 : 0; }
 const char *kge_version(void) { return "kge_mi355 0.1 (gfx950)"; }
 
+int kge_set_option(const char *name, INT value) {
+    std::string n = name ? name : "";
+    if (n == "counts_force_sort") { engine().counts_force_sort = value != 0; return KGE_OK; }
+    return fail(KGE_ERR_BAD_ARG, "kge_set_option: unknown option " + n);
+}
+
 int kge_import_train_arrays(INT ent_total, INT rel_total, INT n, const INT *h, const INT *t, const INT *r,
                             INT new_batch_total) {
     KgIndex ix;

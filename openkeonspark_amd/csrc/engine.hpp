@@ -47,6 +47,7 @@ struct Engine {
     DeviceIndex dev;
     std::string last_error;
     int device_state = 0;  // 0 unknown, 1 ok, -1 none
+    int counts_force_sort = 0;  // test hook: take the sort+segsum reduction even for small tables
 };
 
 Engine &engine();

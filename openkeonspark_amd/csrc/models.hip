@@ -20,36 +20,9 @@
 // Gradients are ADDED into dense per-table accumulators (the deduplicated IndexedSlices sum that
 // TF1 forms before the optimizer) with hardware fp32 atomics.
 #include "engine.hpp"
+#include "team.hpp"
 
 namespace kge {
-
-// ------------------------------------------------------------------------------------------------
-// team reductions
-// ------------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-
-// Sum over the L lanes of the caller's team; every lane of the team receives the total.
-template <int L>
-__device__ __forceinline__ float team_sum(float v) {
-    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2] : lane ^ 1
-    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1] : lane ^ 2
-    v += dpp_f<0x124>(v);  // row_ror:4  (rotations keep the 16-lane row sum uniform)
-    v += dpp_f<0x128>(v);  // row_ror:8
-    if constexpr (L >= 32) {
-        // ds_swizzle bit mode: and=0x1F, or=0, xor=0x10 -> lane ^ 16 inside each 32-lane half
-        v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (0x10 << 10) | 0x1F));
-    }
-    if constexpr (L == 64) {
-        v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
-            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    }
-    return v;
-}
-
-__device__ __forceinline__ float sgn(float x) { return (x > 0.f ? 1.f : 0.f) - (x < 0.f ? 1.f : 0.f); }
 
 struct FbArgs {
     const float *ent, *rel, *auxr, *auxe;  // tables
@@ -64,52 +37,14 @@ struct FbArgs {
     const float *P;
     float *GP;
     int negative_rel;
-};
-
-template <int L, int C>
-struct Team {
-    int lane;  // lane inside the team
-    int D;
-    __device__ __forceinline__ void load(const float *__restrict__ tab, long long row, float (&x)[C]) const {
-        const float *p = tab + row * D;
-#pragma unroll
-        for (int c = 0; c < C; c++) { int e = lane + L * c; x[c] = e < D ? p[e] : 0.f; }
-    }
-    __device__ __forceinline__ void add(float *__restrict__ tab, long long row, const float (&v)[C]) const {
-        float *p = tab + row * D;
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            int e = lane + L * c;
-            if (e < D) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(p + e), v[c]);
-        }
-    }
-    __device__ __forceinline__ void store(float *__restrict__ tab, long long row, const float (&v)[C]) const {
-        float *p = tab + row * D;
-#pragma unroll
-        for (int c = 0; c < C; c++) { int e = lane + L * c; if (e < D) p[e] = v[c]; }
-    }
-    __device__ __forceinline__ float dot(const float (&a)[C], const float (&b)[C]) const {
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < C; c++) s += a[c] * b[c];
-        return team_sum<L>(s);
-    }
-    // tf.nn.l2_normalize: x * rsqrt(max(sum x^2, 1e-12))  (TransE.py:12-14)
-    __device__ __forceinline__ void normalize(const float (&x)[C], float (&y)[C], float &inv, bool &unclipped) const {
-        float ss = dot(x, x);
-        unclipped = ss >= 1e-12f;
-        inv = 1.0f / sqrtf(unclipped ? ss : 1e-12f);
-#pragma unroll
-        for (int c = 0; c < C; c++) y[c] = x[c] * inv;
-    }
-    // backward of normalize: gx = inv * (gy - [unclipped] y <y,gy>)
-    __device__ __forceinline__ void normalize_bwd(const float (&y)[C], const float (&gy)[C], float inv, bool unclipped,
-                                                  float (&gx)[C]) const {
-        float d = dot(y, gy);
-        if (!unclipped) d = 0.f;
-#pragma unroll
-        for (int c = 0; c < C; c++) gx[c] = inv * (gy[c] - d * y[c]);
-    }
+    // TransE sign-count path (transe_counts.hip): int8 gradient records + destination rows
+    uint32_t *rec;
+    int32_t *dst;
+    int ent_total, rel_total, krel;
+    // indirection for the deferred groups of the sign-count path: when group_list != nullptr the
+    // kernel walks group_list[0 .. *group_count) instead of 0 .. n_pos
+    int32_t *group_list;
+    int32_t *group_count;
 };
 
 // One entity side (h or t slot) of a scored triple: raw row(s), projected+normalised vector.
@@ -279,7 +214,9 @@ __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
     tm.D = a.D;
     const int team_in_block = threadIdx.x / L;
     float lsum = 0.f;
-    for (long long b = (long long)blockIdx.x * TEAMS + team_in_block; b < a.n_pos; b += (long long)gridDim.x * TEAMS) {
+    const long long n_groups = a.group_list ? (long long)a.group_count[0] : a.n_pos;
+    for (long long gi = (long long)blockIdx.x * TEAMS + team_in_block; gi < n_groups; gi += (long long)gridDim.x * TEAMS) {
+        const long long b = a.group_list ? (long long)a.group_list[gi] : gi;
         const long long h = a.bh[b], t = a.bt[b], r = a.br[b];
         Ctx<C> cx;
         ctx_forward<MODEL, L, C>(tm, a, r, cx);
@@ -388,6 +325,277 @@ __global__ void loss_finalize_kernel(const float *partials, int n, float unit, f
     if (threadIdx.x == 0) out[0] = sh[0] * unit;
 }
 
+// ------------------------------------------------------------------------------------------------
+// TransE sign-count path, stage 1: same forward as fwdbwd_kernel<TRANSE>, but no atomics.
+//
+// For the L1 score every gradient w.r.t. a NORMALISED vector is (1/denom) x a small integer vector:
+// -/+ sign(e_k) for the new row of an active negative, and cnt*sign(e_p) -/+ sum_k sign(e_k) for the
+// positive's shared h, t, r (|value| <= 2N).  The kernel therefore emits one int8 RECORD per touched
+// row (L*4*ceil(C/4) bytes, one coalesced dword store per lane) plus its destination row id; the sums
+// per destination are exact integers whatever the order (stage 2), and the normalise-backward, which
+// is linear in the upstream gradient, is applied once per ROW on the summed counts (stage 3).
+// Record m = slot*n_pos + b, slot 0/1/2 = the positive's h/t/r, slot 3+k = negative k.
+// Destination row space: entities [0,E), then relation rows spread over `krel` virtual copies
+// E + (b % krel)*R + r so that a hub relation's records do not all land in one reducer.
+// Negatives that are not sampler-shaped take the exact float standalone path into `g_ent/g_rel`
+// (residual accumulators that stay all-zero otherwise).
+// ------------------------------------------------------------------------------------------------
+// --- four int8 lanes per 32-bit word: the integer gradient vectors live packed in registers -----
+__device__ __forceinline__ uint32_t padd8(uint32_t x, uint32_t y) {  // per-byte add, no carry across bytes
+    return ((x & 0x7F7F7F7Fu) + (y & 0x7F7F7F7Fu)) ^ ((x ^ y) & 0x80808080u);
+}
+__device__ __forceinline__ uint32_t pneg8(uint32_t x) { return padd8(~x, 0x01010101u); }  // per-byte two's complement
+// bytes of s are in {-1,0,+1}: per-byte s * cnt, 0 <= cnt <= 127
+__device__ __forceinline__ uint32_t pmul_sign8(uint32_t s, uint32_t cnt) {
+    const uint32_t nz = s & 0x01010101u, neg = (s >> 7) & 0x01010101u;
+    return (nz & ~neg) * cnt + neg * ((256u - cnt) & 0xFFu);
+}
+
+template <int L, int Q>
+__device__ __forceinline__ void store_record(const FbArgs &a, int lane, long long m, const uint32_t (&w)[Q]) {
+    uint32_t *p = a.rec + m * (long long)(L * Q);
+#pragma unroll
+    for (int q = 0; q < Q; q++) p[lane + L * q] = w[q];
+}
+
+// team-uniform broadcast of lane `src` (index inside the team)
+template <int L>
+__device__ __forceinline__ int team_bcast(int v, int src) { return __shfl(v, src, L); }
+
+template <int L, int C>
+__global__ __launch_bounds__(256) void transe_emit_kernel(FbArgs a) {
+    constexpr int TEAMS = 256 / L;
+    constexpr int Q = (C + 3) / 4;
+    constexpr int K = 4;  // negatives processed side by side: 4 row gathers in flight, 4 interleaved reductions
+    __shared__ float red[TEAMS];
+    Team<L, C> tm;
+    tm.lane = threadIdx.x % L;
+    tm.D = a.D;
+    const int team_in_block = threadIdx.x / L;
+    float lsum = 0.f;
+    for (long long b = (long long)blockIdx.x * TEAMS + team_in_block; b < a.n_pos; b += (long long)gridDim.x * TEAMS) {
+        const int h = a.bh[b], t = a.bt[b], r = a.br[b];
+        {   // a group with ANY negative that is not sampler-shaped goes, whole, to the exact fp32 kernel
+            float bad = 0.f;
+            for (int k = tm.lane; k < (int)a.n_neg; k += L) {
+                const long long j = b + (long long)(k + 1) * a.stride;
+                if (!classify_negative<KGE_TRANSE>(h, t, r, a.bh[j], a.bt[j], a.br[j], a.negative_rel).fast) bad = 1.f;
+            }
+            if (team_sum<L>(bad) != 0.f) {
+                if (tm.lane == 0) {
+                    for (long long sl = 0; sl < 3 + a.n_neg; sl++) a.dst[sl * a.n_pos + b] = -1;
+                    a.group_list[atomicAdd(a.group_count, 1)] = (int32_t)b;
+                }
+                continue;
+            }
+        }
+        float hn[C], tn[C], rn[C];
+        {
+            float raw[C], inv; bool uc;
+            tm.load(a.ent, h, raw); tm.normalize(raw, hn, inv, uc);
+            tm.load(a.ent, t, raw); tm.normalize(raw, tn, inv, uc);
+            tm.load(a.rel, r, raw); tm.normalize(raw, rn, inv, uc);
+        }
+        float p;
+        uint32_t sp[Q];  // packed sign(e_p)
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < Q; q++) sp[q] = 0;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float e = hn[c] + rn[c] - tn[c];
+                acc += fabsf(e);
+                sp[c / 4] |= (uint32_t)(((e > 0.f) - (e < 0.f)) & 0xFF) << (8 * (c % 4));
+            }
+            p = team_sum<L>(acc);
+        }
+        uint32_t Ah[Q], At[Q], Ar[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) { Ah[q] = 0; At[q] = 0; Ar[q] = 0; }
+        int cnt = 0;
+        for (int k0 = 0; k0 < (int)a.n_neg; k0 += L) {
+            // ids of up to L negatives, one per lane, classified once (no per-negative scalar loads later)
+            // code: 0 new head, 1 new tail, 2 new relation vector, 3 not sampler-shaped
+            const int my_k = k0 + tm.lane;
+            int my_code = 3, my_row = 0;
+            if (my_k < (int)a.n_neg) {
+                const long long j = b + (long long)(my_k + 1) * a.stride;
+                const int nh = a.bh[j], nt = a.bt[j], nr = a.br[j];
+                const NegClass nc = classify_negative<KGE_TRANSE>(h, t, r, nh, nt, nr, a.negative_rel);
+                if (nc.fast) { my_code = !nc.same_h ? 0 : (!nc.same_t ? 1 : 2); my_row = !nc.same_h ? nh : (!nc.same_t ? nt : nr); }
+            }
+            const int in_round = min(L, (int)a.n_neg - k0);
+            for (int kk = 0; kk < in_round; kk += K) {
+                int code[K], row[K];
+                float x[K][C];
+#pragma unroll
+                for (int u = 0; u < K; u++) {
+                    const int src = min(kk + u, in_round - 1);
+                    code[u] = team_bcast<L>(my_code, src);
+                    row[u] = team_bcast<L>(my_row, src);
+                }
+#pragma unroll
+                for (int u = 0; u < K; u++)   // unconditional gathers (a padded slot re-reads a valid row): all K in flight
+                    tm.load(code[u] == 2 ? a.rel : a.ent, row[u], x[u]);
+#pragma unroll
+                for (int u = 0; u < K; u++) if (kk + u >= in_round) code[u] = -1;
+                float ss[K];
+#pragma unroll
+                for (int u = 0; u < K; u++) {
+                    float sq = 0.f;
+                    if (code[u] >= 0) {
+#pragma unroll
+                        for (int c = 0; c < C; c++) sq += x[u][c] * x[u][c];
+                    }
+                    ss[u] = sq;
+                }
+#pragma unroll
+                for (int u = 0; u < K; u++) ss[u] = team_sum<L>(ss[u]);
+                float sc[K];
+                uint32_t sg[K][Q];  // packed sign(e_k)
+#pragma unroll
+                for (int u = 0; u < K; u++) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int q = 0; q < Q; q++) sg[u][q] = 0;
+                    if (code[u] >= 0) {
+                        const float inv = 1.0f / sqrtf(ss[u] >= 1e-12f ? ss[u] : 1e-12f);
+#pragma unroll
+                        for (int c = 0; c < C; c++) {
+                            const float xn = x[u][c] * inv;
+                            const float e = code[u] == 0 ? xn + rn[c] - tn[c] : (code[u] == 1 ? hn[c] + rn[c] - xn : hn[c] + xn - tn[c]);
+                            acc += fabsf(e);
+                            sg[u][c / 4] |= (uint32_t)(((e > 0.f) - (e < 0.f)) & 0xFF) << (8 * (c % 4));
+                        }
+                    }
+                    sc[u] = acc;
+                }
+#pragma unroll
+                for (int u = 0; u < K; u++) sc[u] = team_sum<L>(sc[u]);
+#pragma unroll
+                for (int u = 0; u < K; u++) {
+                    if (code[u] < 0) continue;
+                    const long long m = (3 + k0 + kk + u) * a.n_pos + b;
+                    const float v = p - sc[u] + a.margin;
+                    long long dest = -1;
+                    if (v >= 0.f) {
+                        cnt++; lsum += v;
+                        uint32_t rec[Q];
+                        if (code[u] == 0) {         // new head: dL/dx^ = -unit*s ; kept t gets +s, r gets -s
+#pragma unroll
+                            for (int q = 0; q < Q; q++) { const uint32_t ns = pneg8(sg[u][q]); rec[q] = ns; At[q] = padd8(At[q], sg[u][q]); Ar[q] = padd8(Ar[q], ns); }
+                            dest = row[u];
+                        } else if (code[u] == 1) {  // new tail: +unit*s ; kept h gets -s, r gets -s
+#pragma unroll
+                            for (int q = 0; q < Q; q++) { const uint32_t ns = pneg8(sg[u][q]); rec[q] = sg[u][q]; Ah[q] = padd8(Ah[q], ns); Ar[q] = padd8(Ar[q], ns); }
+                            dest = row[u];
+                        } else {                    // new relation vector: -unit*s ; h gets -s, t gets +s
+#pragma unroll
+                            for (int q = 0; q < Q; q++) { const uint32_t ns = pneg8(sg[u][q]); rec[q] = ns; Ah[q] = padd8(Ah[q], ns); At[q] = padd8(At[q], sg[u][q]); }
+                            dest = (long long)a.ent_total + row[u];
+                        }
+                        store_record<L, Q>(a, tm.lane, m, rec);
+                    }
+                    if (tm.lane == 0) a.dst[m] = (int32_t)dest;
+                }
+            }
+        }
+        if (cnt > 0) {
+            uint32_t rh[Q], rt[Q], rr[Q];
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const uint32_t sv = pmul_sign8(sp[q], (uint32_t)cnt);
+                rh[q] = padd8(Ah[q], sv); rt[q] = padd8(At[q], pneg8(sv)); rr[q] = padd8(Ar[q], sv);
+            }
+            store_record<L, Q>(a, tm.lane, b, rh);
+            store_record<L, Q>(a, tm.lane, a.n_pos + b, rt);
+            store_record<L, Q>(a, tm.lane, 2 * a.n_pos + b, rr);
+        }
+        if (tm.lane == 0) {
+            a.dst[b] = cnt > 0 ? (int32_t)h : -1;
+            a.dst[a.n_pos + b] = cnt > 0 ? (int32_t)t : -1;
+            a.dst[2 * a.n_pos + b] = cnt > 0 ? (int32_t)(a.ent_total + r) : -1;
+        }
+    }
+    if (tm.lane == 0) red[team_in_block] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < TEAMS; i++) s += red[i];
+        a.loss_partials[blockIdx.x] = s;
+    }
+}
+
+constexpr int kDeferBlocks = 128;
+
+template <int L, int C>
+static void launch_emit(const FbArgs &a, float *d_loss, hipStream_t stream) {
+    constexpr int TEAMS = 256 / L;
+    long long blocks = (a.n_pos + TEAMS - 1) / TEAMS;
+    if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
+    if (blocks < 1) blocks = 1;
+    FbArgs e = a;
+    e.group_list = a.group_list;  // emit APPENDS deferred groups here
+    hipLaunchKernelGGL((transe_emit_kernel<L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, e);
+    // groups with non sampler-shaped negatives: exact fp32 path into the residual accumulators
+    FbArgs d = a;
+    d.loss_partials = a.loss_partials + blocks;
+    hipLaunchKernelGGL((fwdbwd_kernel<KGE_TRANSE, L, C>), dim3(kDeferBlocks), dim3(256), 0, stream, d);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, a.loss_partials, (int)blocks + kDeferBlocks, a.unit, d_loss);
+}
+
+// team shape used for dimension D (shared with transe_counts.hip through these two helpers)
+void transe_team_shape(int D, int &L, int &C) {
+    if (D <= 16) { L = 16; C = 1; } else if (D <= 32) { L = 16; C = 2; } else if (D <= 64) { L = 16; C = 4; }
+    else if (D <= 128) { L = 32; C = 4; } else if (D <= 256) { L = 64; C = 4; } else if (D <= 512) { L = 64; C = 8; }
+    else { L = 64; C = 16; }
+}
+
+int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *rel, float *resid_ent, float *resid_rel,
+                       const int32_t *d_h, const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
+                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream) {
+    Engine &e = engine();
+    if (!e.dev.loss_partials) {
+        int rc = hip_check(hipMalloc(&e.dev.loss_partials, sizeof(float) * (kMaxLossBlocks + 256)), "alloc loss partials");
+        if (rc) return rc;
+    }
+    static int32_t *defer_list = nullptr, *defer_count = nullptr;
+    static int64_t defer_cap = 0;
+    if (n_pos > defer_cap) {
+        if (defer_list) (void)hipFree(defer_list);
+        defer_list = nullptr;
+        int rc = hip_check(hipMalloc(&defer_list, sizeof(int32_t) * (size_t)n_pos), "alloc deferred groups");
+        if (rc) return rc;
+        if (!defer_count && (rc = hip_check(hipMalloc(&defer_count, sizeof(int32_t)), "alloc deferred count"))) return rc;
+        defer_cap = n_pos;
+    }
+    {
+        int rc = hip_check(hipMemsetAsync(defer_count, 0, sizeof(int32_t), stream), "zero deferred count");
+        if (rc) return rc;
+    }
+    FbArgs a = {};
+    a.group_list = defer_list; a.group_count = defer_count;
+    a.ent = ent; a.rel = rel; a.g_ent = resid_ent; a.g_rel = resid_rel;
+    a.bh = d_h; a.bt = d_t; a.br = d_r;
+    a.n_pos = n_pos; a.n_neg = n_neg; a.stride = stride;
+    a.D = m.ent_dim; a.margin = m.margin; a.unit = 1.0f / (float)denom;
+    a.loss_partials = e.dev.loss_partials;
+    a.negative_rel = m.negative_rel;
+    a.rec = rec; a.dst = dst; a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total; a.krel = krel;
+    const int D = a.D;
+    if (D <= 16) launch_emit<16, 1>(a, d_loss, stream);
+    else if (D <= 32) launch_emit<16, 2>(a, d_loss, stream);
+    else if (D <= 64) launch_emit<16, 4>(a, d_loss, stream);
+    else if (D <= 128) launch_emit<32, 4>(a, d_loss, stream);
+    else if (D <= 256) launch_emit<64, 4>(a, d_loss, stream);
+    else if (D <= 512) launch_emit<64, 8>(a, d_loss, stream);
+    else if (D <= 1024) launch_emit<64, 16>(a, d_loss, stream);
+    else return fail(KGE_ERR_UNSUPPORTED, "embedding dimension > 1024");
+    return hip_check(hipGetLastError(), "transe emit launch");
+}
+
 template <int MODEL, int L, int C>
 static void launch_fb(const FbArgs &a, float *d_loss, hipStream_t stream) {
     constexpr int TEAMS = 256 / L;
@@ -441,13 +649,13 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
     if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_forward_backward: no usable HIP device");
     if (n_pos < 0 || n_neg < 1 || stride < n_pos || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_forward_backward: bad sizes");
     if (!e.dev.loss_partials) {
-        int rc = hip_check(hipMalloc(&e.dev.loss_partials, sizeof(float) * kMaxLossBlocks), "alloc loss partials");
+        int rc = hip_check(hipMalloc(&e.dev.loss_partials, sizeof(float) * (kMaxLossBlocks + 256)), "alloc loss partials");
         if (rc) return rc;
     }
     if (m.model == KGE_TRANSR)
         return launch_forward_backward_transr(m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, grads, d_loss, stream);
     if (m.ent_dim != m.rel_dim) return fail(KGE_ERR_BAD_ARG, "TransE/H/D need ent_dim == rel_dim (hidden_size)");
-    FbArgs a;
+    FbArgs a = {};
     a.ent = tables[0]; a.rel = tables[1]; a.auxr = tables[2]; a.auxe = tables[3];
     a.g_ent = grads[0]; a.g_rel = grads[1]; a.g_auxr = grads[2]; a.g_auxe = grads[3];
     a.bh = d_h; a.bt = d_t; a.br = d_r;

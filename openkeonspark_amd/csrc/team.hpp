@@ -1,0 +1,85 @@
+// Device-side team primitives shared by the vector-model kernels (models.hip) and the TransE
+// sign-count path (transe_counts.hip): a TEAM of L lanes (16/32/64) owns one embedding vector, lane l
+// holding elements l, l+L, l+2L, ...; reductions over the embedding dimension are DPP / swizzle
+// butterflies, no LDS traffic.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace kge {
+
+// ------------------------------------------------------------------------------------------------
+// team reductions
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+
+// Sum over the L lanes of the caller's team; every lane of the team receives the total.
+template <int L>
+__device__ __forceinline__ float team_sum(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2] : lane ^ 1
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1] : lane ^ 2
+    v += dpp_f<0x124>(v);  // row_ror:4  (rotations keep the 16-lane row sum uniform)
+    v += dpp_f<0x128>(v);  // row_ror:8
+    if constexpr (L >= 32) {
+        // ds_swizzle bit mode: and=0x1F, or=0, xor=0x10 -> lane ^ 16 inside each 32-lane half
+        v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (0x10 << 10) | 0x1F));
+    }
+    if constexpr (L == 64) {
+        v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    }
+    return v;
+}
+
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f ? 1.f : 0.f) - (x < 0.f ? 1.f : 0.f); }
+
+template <int L, int C>
+struct Team {
+    int lane;  // lane inside the team
+    int D;
+    __device__ __forceinline__ void load(const float *__restrict__ tab, long long row, float (&x)[C]) const {
+        const float *p = tab + row * D;
+#pragma unroll
+        for (int c = 0; c < C; c++) { int e = lane + L * c; x[c] = e < D ? p[e] : 0.f; }
+    }
+    __device__ __forceinline__ void add(float *__restrict__ tab, long long row, const float (&v)[C]) const {
+        float *p = tab + row * D;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            int e = lane + L * c;
+            if (e < D) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(p + e), v[c]);
+        }
+    }
+    __device__ __forceinline__ void store(float *__restrict__ tab, long long row, const float (&v)[C]) const {
+        float *p = tab + row * D;
+#pragma unroll
+        for (int c = 0; c < C; c++) { int e = lane + L * c; if (e < D) p[e] = v[c]; }
+    }
+    __device__ __forceinline__ float dot(const float (&a)[C], const float (&b)[C]) const {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) s += a[c] * b[c];
+        return team_sum<L>(s);
+    }
+    // tf.nn.l2_normalize: x * rsqrt(max(sum x^2, 1e-12))  (TransE.py:12-14)
+    __device__ __forceinline__ void normalize(const float (&x)[C], float (&y)[C], float &inv, bool &unclipped) const {
+        float ss = dot(x, x);
+        unclipped = ss >= 1e-12f;
+        inv = 1.0f / sqrtf(unclipped ? ss : 1e-12f);
+#pragma unroll
+        for (int c = 0; c < C; c++) y[c] = x[c] * inv;
+    }
+    // backward of normalize: gx = inv * (gy - [unclipped] y <y,gy>)
+    __device__ __forceinline__ void normalize_bwd(const float (&y)[C], const float (&gy)[C], float inv, bool unclipped,
+                                                  float (&gx)[C]) const {
+        float d = dot(y, gy);
+        if (!unclipped) d = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) gx[c] = inv * (gy[c] - d * y[c]);
+    }
+};
+
+
+}  // namespace kge

@@ -1,0 +1,488 @@
+// TransE sign-count gradient path, stages 2 and 3 (stage 1, the emit kernel, lives in models.hip).
+//
+// Why: the generic path adds one fp32 gradient row per touched row with memory-side atomics, and
+// those run at ~1.1 TB/s on MI355X whatever the access pattern (experiments/atomic_bench.hip), 6-7x
+// below plain stores -- the fused kernel was pinned to that floor (profiles/r01_a_*).  For TransE the
+// upstream gradient of every NORMALISED vector is an integer multiple of 1/denom (sign vectors), so
+// stage 1 emits 4x smaller int8 records with plain coalesced stores, and the reduction is exact
+// integer arithmetic: order-independent, bit-reproducible, and identical on every data-parallel
+// replica.
+//
+//   stage 2a  stable radix sort of (destination row, record id) pairs                    (rocPRIM)
+//   stage 2b  segsum_kernel: one team per CHUNK of 64 sorted records; runs of equal destination are
+//             summed in registers; a run that lies inside the chunk is STORED, only the first/last
+//             run of a chunk (which may continue in the neighbour) is added with int32 atomics -- hub
+//             rows are thus spread over many teams and ~1/64 of the records' bytes touch an atomic.
+//   stage 3   apply_counts_kernel: per ROW, g = (1/denom) * inv * (S - x^ <x^,S>) + residual, then SGD
+//             or TF1-semantics Adam in place, counts re-zeroed.  The normalise-backward is linear in
+//             the upstream gradient, so applying it once to the summed counts equals the sum of the
+//             per-use backward passes of the reference graph (TransE.py:12-15).
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "engine.hpp"
+#include "team.hpp"
+
+namespace kge {
+
+void transe_team_shape(int D, int &L, int &C);
+int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *rel, float *resid_ent, float *resid_rel,
+                       const int32_t *d_h, const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
+                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream);
+
+namespace {
+
+struct CtWork {
+    uint32_t *rec = nullptr;
+    int32_t *dst = nullptr, *dst_sorted = nullptr, *ids = nullptr, *ids_sorted = nullptr;
+    int32_t *n_valid = nullptr;
+    int32_t *tile_hist = nullptr, *bucket_start = nullptr;   // LDS-bucket path: bucket totals + cursors, bucket starts
+    int32_t *pairs = nullptr;                                  // [2*cap] (record id, destination) grouped by bucket
+    int64_t cap_hist = 0;
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0, rec_dwords = 0;
+    int64_t cap_rec = 0;
+};
+CtWork g_c;
+
+template <typename T>
+int regrow(T *&p, size_t count, const char *what) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    return hip_check(hipMalloc(&p, sizeof(T) * (count ? count : 1)), what);
+}
+
+int ensure_counts_work(int64_t M, size_t rec_dwords) {
+    int rc;
+    if (M > g_c.cap_rec || rec_dwords > g_c.rec_dwords) {
+        int64_t cap = M > g_c.cap_rec ? M : g_c.cap_rec;
+        size_t rd = rec_dwords > g_c.rec_dwords ? rec_dwords : g_c.rec_dwords;
+        if ((rc = regrow(g_c.rec, (size_t)cap * rd, "counts records"))) return rc;
+        if ((rc = regrow(g_c.dst, (size_t)cap, "counts dst"))) return rc;
+        if ((rc = regrow(g_c.dst_sorted, (size_t)cap, "counts dst_sorted"))) return rc;
+        if ((rc = regrow(g_c.ids, (size_t)cap, "counts ids"))) return rc;
+        if ((rc = regrow(g_c.ids_sorted, (size_t)cap, "counts ids_sorted"))) return rc;
+        if ((rc = regrow(g_c.pairs, (size_t)cap * 2, "counts pairs"))) return rc;
+        if (!g_c.n_valid && (rc = regrow(g_c.n_valid, 1, "counts n_valid"))) return rc;
+        size_t bytes = 0;
+        (void)rocprim::radix_sort_pairs(nullptr, bytes, g_c.dst, g_c.dst_sorted, g_c.ids, g_c.ids_sorted, (size_t)cap, 0, 32, nullptr);
+        if (bytes > g_c.sort_tmp_bytes) {
+            if (g_c.sort_tmp) (void)hipFree(g_c.sort_tmp);
+            g_c.sort_tmp = nullptr;
+            if ((rc = hip_check(hipMalloc(&g_c.sort_tmp, bytes), "counts sort temp"))) return rc;
+            g_c.sort_tmp_bytes = bytes;
+        }
+        // record ids 0..cap-1 never change
+        std::vector<int32_t> iota((size_t)cap);
+        for (int64_t i = 0; i < cap; i++) iota[(size_t)i] = (int32_t)i;
+        if ((rc = hip_check(hipMemcpy(g_c.ids, iota.data(), sizeof(int32_t) * (size_t)cap, hipMemcpyHostToDevice), "counts iota"))) return rc;
+        g_c.cap_rec = cap; g_c.rec_dwords = rd;
+    }
+    return KGE_OK;
+}
+
+// destination -1 (inactive / no record) is remapped to the sentinel key `rows` so it sorts last
+__global__ void fix_keys_kernel(int32_t *dst, long long M, int sentinel) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long)gridDim.x * blockDim.x)
+        if (dst[i] < 0) dst[i] = sentinel;
+}
+
+__global__ void count_valid_kernel(const int32_t *__restrict__ sorted, int M, int sentinel, int32_t *n_valid) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int lo = 0, hi = M;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (sorted[mid] < sentinel) lo = mid + 1; else hi = mid; }
+        n_valid[0] = lo;
+    }
+}
+
+constexpr int CHUNK = 64;
+
+template <int L, int C>
+__device__ __forceinline__ void flush_run(int32_t *__restrict__ S, int D, int lane, long long row, const int (&acc)[C], bool atomic) {
+    int32_t *p = S + row * D;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int e = lane + L * c;
+        if (e < D) {
+            if (atomic) { if (acc[c] != 0) atomicAdd(p + e, acc[c]); }
+            else p[e] = acc[c];
+        }
+    }
+}
+
+template <int L, int C>
+__global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict__ rec, const int32_t *__restrict__ keys,
+                                                     const int32_t *__restrict__ ids, const int32_t *__restrict__ n_valid_p,
+                                                     int32_t *__restrict__ S, int D) {
+    constexpr int TEAMS = 256 / L;
+    constexpr int Q = (C + 3) / 4;
+    constexpr int RD = L * Q;
+    const int lane = threadIdx.x % L;
+    const int n_valid = n_valid_p[0];
+    const long long chunk = (long long)blockIdx.x * TEAMS + threadIdx.x / L;
+    const long long start = chunk * CHUNK;
+    if (start >= n_valid) return;
+    const int n = (int)min((long long)CHUNK, n_valid - start);
+    int acc[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) acc[c] = 0;
+    int cur = keys[start];
+    bool first_run = true;
+    constexpr int U = 8;  // records in flight per team
+    for (int i0 = 0; i0 < n; i0 += U) {
+        int k[U], id[U];
+        uint32_t w[U][Q];
+#pragma unroll
+        for (int u = 0; u < U; u++) {   // unconditional (clamped) loads: all in flight together
+            const int i = min(i0 + u, n - 1);
+            k[u] = keys[start + i];
+            id[u] = ids[start + i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t *p = rec + (long long)id[u] * RD;
+#pragma unroll
+            for (int q = 0; q < Q; q++) w[u][q] = p[lane + L * q];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) if (i0 + u >= n) k[u] = -1;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (k[u] < 0) break;
+            if (k[u] != cur) {
+                flush_run<L, C>(S, D, lane, cur, acc, first_run);
+#pragma unroll
+                for (int c = 0; c < C; c++) acc[c] = 0;
+                cur = k[u];
+                first_run = false;
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int c = 4 * q + j;
+                    if (c < C) acc[c] += (int)(int8_t)(w[u][q] >> (8 * j));
+                }
+        }
+    }
+    flush_run<L, C>(S, D, lane, cur, acc, true);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Small row spaces (FB15k-237-sized tables): bucket the records by destination RANGE with one
+// counting pass (NB buckets of `rpb` consecutive rows), then one workgroup per bucket accumulates
+// its records into an int32 LDS image of its rows (ds_add, conflict-free: consecutive lanes hit
+// consecutive dwords) and writes the rows out with plain coalesced stores.  No global atomics at
+// all, no comparison sort; the order inside a bucket is irrelevant because the sums are integers.
+// ---------------------------------------------------------------------------------------------
+constexpr int NB = 512;          // buckets (+1 trash bucket for inactive records)
+constexpr int BTILE = 4096;      // records per histogram / scatter tile
+
+__device__ __forceinline__ int bucket_of(int d, int rpb) { return d < 0 ? NB : d / rpb; }
+
+// bucket_total[b] += number of records of this tile that fall into bucket b
+__global__ __launch_bounds__(256) void bkt_hist_kernel(const int32_t *__restrict__ dst, int M, int rpb, int32_t *__restrict__ bucket_total) {
+    __shared__ int hist[NB + 1];
+    for (int i = threadIdx.x; i <= NB; i += 256) hist[i] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * BTILE;
+    for (int i = threadIdx.x; i < BTILE; i += 256) {
+        const int m = base + i;
+        if (m < M) atomicAdd(&hist[bucket_of(dst[m], rpb)], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= NB; i += 256)
+        if (hist[i]) atomicAdd(&bucket_total[i], hist[i]);
+}
+
+// exclusive scan of the NB+1 bucket totals -> bucket_start[0..NB+1]; cursors start there; totals re-zeroed
+__global__ __launch_bounds__(1024) void bkt_scan_kernel(int32_t *__restrict__ bucket_total, int32_t *__restrict__ bucket_start,
+                                                        int32_t *__restrict__ cursor) {
+    __shared__ int buf[1024];
+    const int t = threadIdx.x;
+    const int v = t <= NB ? bucket_total[t] : 0;
+    buf[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+        const int add = t >= off ? buf[t - off] : 0;
+        __syncthreads();
+        buf[t] += add;
+        __syncthreads();
+    }
+    if (t <= NB) {
+        const int excl = buf[t] - v;
+        bucket_start[t] = excl;
+        cursor[t] = excl;
+        bucket_total[t] = 0;
+        if (t == NB) bucket_start[NB + 1] = buf[t];
+    }
+}
+
+// (record id, destination row) pairs grouped by bucket; the order inside a bucket is arbitrary
+__global__ __launch_bounds__(256) void bkt_scatter_kernel(const int32_t *__restrict__ dst, int M, int rpb,
+                                                          int32_t *__restrict__ cursor, int2 *__restrict__ pairs) {
+    __shared__ int hist[NB + 1];
+    __shared__ int base_of[NB + 1];
+    for (int i = threadIdx.x; i <= NB; i += 256) hist[i] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * BTILE;
+    int d[BTILE / 256];
+#pragma unroll
+    for (int k = 0; k < BTILE / 256; k++) {
+        const int m = base + threadIdx.x + 256 * k;
+        d[k] = m < M ? dst[m] : -2;
+        if (m < M) atomicAdd(&hist[bucket_of(d[k], rpb)], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= NB; i += 256) {
+        const int c = hist[i];
+        base_of[i] = c ? atomicAdd(&cursor[i], c) : 0;   // reserve this tile's range in bucket i
+        hist[i] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BTILE / 256; k++) {
+        const int m = base + threadIdx.x + 256 * k;
+        if (m < M && d[k] >= 0) {
+            const int bk = bucket_of(d[k], rpb);
+            const int pos = base_of[bk] + atomicAdd(&hist[bk], 1);
+            pairs[pos] = make_int2(m, d[k]);
+        }
+    }
+}
+
+template <int L, int Q>
+__global__ __launch_bounds__(512) void bkt_reduce_kernel(const uint32_t *__restrict__ rec, const int2 *__restrict__ pairs,
+                                                         const int32_t *__restrict__ bucket_start, int rpb, int rows, int D,
+                                                         int32_t *__restrict__ S) {
+    extern __shared__ int lds_S[];
+    constexpr int RD = L * Q;
+    const int b = blockIdx.x;
+    const int row0 = b * rpb;
+    const int nrows = min(rpb, rows - row0);
+    if (nrows <= 0) return;
+    for (int i = threadIdx.x; i < nrows * D; i += blockDim.x) lds_S[i] = 0;
+    __syncthreads();
+    const int start = bucket_start[b], end = bucket_start[b + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    constexpr int RPW = RD >= 64 ? 1 : 64 / RD;      // records handled side by side by one wave
+    constexpr int WPL = RD >= 64 ? RD / 64 : 1;      // dwords per lane per record
+    const int sub = RD >= 64 ? 0 : lane / RD;
+    const int w0 = RD >= 64 ? lane : lane % RD;
+    constexpr int U = 8;                              // record loads in flight per wave
+    for (int i0 = start + wave * (RPW * U); i0 < end; i0 += nwaves * RPW * U) {
+        // loads are unconditional (index clamped) and issued in two batches -- all pairs, then all
+        // records -- so 8 independent requests are in flight per wave instead of 16 serialised ones
+        int2 pr[U];
+        int drow[U];
+        uint32_t w[U][WPL];
+#pragma unroll
+        for (int u = 0; u < U; u++) pr[u] = pairs[min(i0 + u * RPW + sub, end - 1)];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t *p = rec + (long long)pr[u].x * RD;
+#pragma unroll
+            for (int x = 0; x < WPL; x++) w[u][x] = p[w0 + 64 * x];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) drow[u] = (i0 + u * RPW + sub < end) ? pr[u].y - row0 : -1;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (drow[u] < 0) continue;
+            int *Srow = lds_S + drow[u] * D;
+#pragma unroll
+            for (int x = 0; x < WPL; x++) {
+                const int wd = w0 + 64 * x;
+                const int q = wd / L, l = wd - q * L;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int e = l + L * (4 * q + j);
+                    const int v = (int)(int8_t)(w[u][x] >> (8 * j));
+                    if (e < D && v != 0) atomicAdd(&Srow[e], v);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int32_t *out = S + (long long)row0 * D;
+    for (int i = threadIdx.x; i < nrows * D; i += blockDim.x) out[i] = lds_S[i];
+}
+
+// stage 3.  optimizer: 0 = SGD (lr), 1 = Adam (lr = lr_t)
+struct ApplyArgs {
+    float *p, *m, *v;
+    int32_t *S;
+    float *resid;
+    long long rows;
+    int D;
+    float unit, lr, b1, b2, eps;
+    int adam;
+};
+
+template <int L, int C>
+__global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
+    constexpr int TEAMS = 256 / L;
+    Team<L, C> tm;
+    tm.lane = threadIdx.x % L;
+    tm.D = a.D;
+    for (long long row = (long long)blockIdx.x * TEAMS + threadIdx.x / L; row < a.rows; row += (long long)gridDim.x * TEAMS) {
+        int32_t *Sp = a.S + row * a.D;
+        float *rp = a.resid + row * a.D;
+        float s[C], rs[C];
+        float touched = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int e = tm.lane + L * c;
+            const int si = e < a.D ? Sp[e] : 0;
+            rs[c] = e < a.D ? rp[e] : 0.f;
+            s[c] = (float)si;
+            touched += (si != 0 || rs[c] != 0.f) ? 1.f : 0.f;
+        }
+        touched = team_sum<L>(touched);
+        if (touched == 0.f && !a.adam) continue;  // SGD leaves untouched rows alone; TF1 Adam moves every row
+        float x[C], g[C];
+        tm.load(a.p, row, x);
+        if (touched != 0.f) {
+            float xn[C], inv; bool uc;
+            tm.normalize(x, xn, inv, uc);
+            float d = tm.dot(xn, s);
+            if (!uc) d = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; c++) g[c] = a.unit * inv * (s[c] - d * xn[c]) + rs[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; c++) g[c] = 0.f;
+        }
+        float *pp = a.p + row * a.D;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int e = tm.lane + L * c;
+            if (e >= a.D) continue;
+            if (a.adam) {
+                float *mp = a.m + row * a.D + e, *vp = a.v + row * a.D + e;
+                float mi = __fmul_rn(*mp, a.b1), vi = __fmul_rn(*vp, a.b2);
+                if (g[c] != 0.f) {
+                    mi = __fadd_rn(mi, __fmul_rn(g[c], 1.0f - a.b1));
+                    vi = __fadd_rn(vi, __fmul_rn(__fmul_rn(g[c], g[c]), 1.0f - a.b2));
+                }
+                *mp = mi; *vp = vi;
+                pp[e] = __fsub_rn(x[c], __fdiv_rn(__fmul_rn(a.lr, mi), __fadd_rn(__fsqrt_rn(vi), a.eps)));
+            } else if (g[c] != 0.f) {
+                pp[e] = x[c] - a.lr * g[c];
+            }
+            if (touched != 0.f) { Sp[e] = 0; if (rs[c] != 0.f) rp[e] = 0.f; }
+        }
+    }
+}
+
+#define KGE_SHAPE_DISPATCH(D, CALL)                                      \
+    if (D <= 16) { CALL(16, 1); } else if (D <= 32) { CALL(16, 2); }     \
+    else if (D <= 64) { CALL(16, 4); } else if (D <= 128) { CALL(32, 4); } \
+    else if (D <= 256) { CALL(64, 4); } else if (D <= 512) { CALL(64, 8); } \
+    else { CALL(64, 16); }
+
+int bits_for_rows(int64_t v) { int b = 1; while ((int64_t(1) << b) <= v) b++; return b; }
+
+}  // namespace
+
+}  // namespace kge
+
+using namespace kge;
+
+extern "C" {
+
+int kge_transe_counts_supported(const kge_model_desc *m, INT n_neg) {
+    if (!m) return 0;
+    return m->model == KGE_TRANSE && m->ent_dim == m->rel_dim && m->ent_dim <= 1024 && n_neg >= 1 && n_neg <= 63 &&
+           m->ent_total + m->rel_total < (int64_t(1) << 30);
+}
+
+int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const float *d_rel, const int32_t *d_h,
+                              const int32_t *d_t, const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom,
+                              int32_t *d_counts, float *d_resid_ent, float *d_resid_rel, float *d_loss, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_forward_counts: no usable HIP device");
+    if (!m || !kge_transe_counts_supported(m, n_neg)) return fail(KGE_ERR_UNSUPPORTED, "sign-count path: TransE, dim <= 1024, 1..63 negatives");
+    if (n_pos < 0 || stride < n_pos || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_transe_forward_counts: bad sizes");
+    if (n_pos == 0) return hip_check(hipMemsetAsync(d_loss, 0, sizeof(float), stream), "zero loss");
+    int L, C;
+    transe_team_shape(m->ent_dim, L, C);
+    const size_t rd = (size_t)L * ((C + 3) / 4);
+    const int64_t M = n_pos * (3 + n_neg);
+    if (M >= (int64_t(1) << 31)) return fail(KGE_ERR_UNSUPPORTED, "batch too large for the sign-count path");
+    int rc = ensure_counts_work(M, rd);
+    if (rc) return rc;
+    const int rows = (int)(m->ent_total + m->rel_total);
+    // krel = 1: relation rows are ordinary rows E + r of the one row space (hub rows are split by the chunking)
+    rc = launch_transe_emit(*m, d_ent, d_rel, d_resid_ent, d_resid_rel, d_h, d_t, d_r, n_pos, n_neg, stride, denom, g_c.rec, g_c.dst,
+                            1, d_loss, stream);
+    if (rc) return rc;
+    const int D = m->ent_dim;
+    const int rpb = (rows + NB - 1) / NB;
+    const size_t lds_bytes = (size_t)rpb * D * sizeof(int);
+    if (lds_bytes <= 64 * 1024 && !engine().counts_force_sort) {
+        // ---- LDS-bucket reduce (small row spaces) ----
+        const int n_tiles = (int)((M + BTILE - 1) / BTILE);
+        if (!g_c.bucket_start) {
+            if ((rc = regrow(g_c.bucket_start, NB + 2, "counts bucket_start"))) return rc;
+            if ((rc = regrow(g_c.tile_hist, 2 * (NB + 2), "counts bucket totals/cursors"))) return rc;
+            if ((rc = hip_check(hipMemset(g_c.tile_hist, 0, sizeof(int32_t) * 2 * (NB + 2)), "zero bucket totals"))) return rc;
+        }
+        int32_t *totals = g_c.tile_hist, *cursor = g_c.tile_hist + (NB + 2);
+        int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
+        hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals);
+        hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(1024), 0, stream, totals, g_c.bucket_start, cursor);
+        hipLaunchKernelGGL(bkt_scatter_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, cursor, pairs);
+#define KGE_BKT(LL, CC)                                                                                                  \
+        hipLaunchKernelGGL((bkt_reduce_kernel<LL, (CC + 3) / 4>), dim3(NB), dim3(512), lds_bytes, stream, g_c.rec, pairs, \
+                           g_c.bucket_start, rpb, rows, D, d_counts);
+        KGE_SHAPE_DISPATCH(D, KGE_BKT)
+#undef KGE_BKT
+        return hip_check(hipGetLastError(), "counts bucket reduce launch");
+    }
+    // ---- general path: sort + segmented sum (large row spaces) ----
+    int blocks = (int)((M + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fix_keys_kernel, dim3(blocks), dim3(256), 0, stream, g_c.dst, (long long)M, rows);
+    size_t tmp = g_c.sort_tmp_bytes;
+    rc = hip_check(rocprim::radix_sort_pairs(g_c.sort_tmp, tmp, g_c.dst, g_c.dst_sorted, g_c.ids, g_c.ids_sorted, (size_t)M, 0,
+                                             bits_for_rows(rows), stream), "counts sort");
+    if (rc) return rc;
+    hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(64), 0, stream, g_c.dst_sorted, (int)M, rows, g_c.n_valid);
+#define KGE_SEG(LL, CC)                                                                                               \
+    {                                                                                                                 \
+        const long long chunks = (M + CHUNK - 1) / CHUNK;                                                             \
+        const long long nb = (chunks + (256 / LL) - 1) / (256 / LL);                                                  \
+        hipLaunchKernelGGL((segsum_kernel<LL, CC>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec, g_c.dst_sorted, \
+                           g_c.ids_sorted, g_c.n_valid, d_counts, D);                                                 \
+    }
+    KGE_SHAPE_DISPATCH(D, KGE_SEG)
+#undef KGE_SEG
+    return hip_check(hipGetLastError(), "counts reduce launch");
+}
+
+int kge_transe_apply_counts(float *d_p, float *d_m, float *d_v, int32_t *d_counts, float *d_resid, int64_t rows, int32_t dim,
+                            INT denom, int32_t adam, float lr, float beta1, float beta2, float eps, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_apply_counts: no usable HIP device");
+    if (rows <= 0) return KGE_OK;
+    if (dim > 1024 || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_counts: bad sizes");
+    ApplyArgs a;
+    a.p = d_p; a.m = d_m; a.v = d_v; a.S = d_counts; a.resid = d_resid; a.rows = rows; a.D = dim;
+    a.unit = 1.0f / (float)denom; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.adam = adam;
+    const int D = dim;
+#define KGE_APPLY(LL, CC)                                                                                   \
+    {                                                                                                       \
+        long long nb = (rows + (256 / LL) - 1) / (256 / LL);                                                \
+        if (nb > 4096) nb = 4096;                                                                           \
+        hipLaunchKernelGGL((apply_counts_kernel<LL, CC>), dim3((unsigned)nb), dim3(256), 0, stream, a);     \
+    }
+    KGE_SHAPE_DISPATCH(D, KGE_APPLY)
+#undef KGE_APPLY
+    return hip_check(hipGetLastError(), "apply counts launch");
+}
+
+}  // extern "C"

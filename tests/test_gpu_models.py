@@ -17,7 +17,9 @@ def relerr(a, b):
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
 
 
-def rand_batch(rng, E, R, B, n, nr, foreign=0.0):
+def rand_batch(rng, E, R, B, n, nr, foreign=0.0, distinct=False):
+    """distinct=True: a corrupted slot always differs from the positive's (as the reference's filtered
+    sampler guarantees); otherwise a negative may coincide with its positive by chance."""
     N = n + nr
     h = np.zeros(B * (1 + N), np.int64); t = h.copy(); r = h.copy()
     h[:B] = rng.integers(0, E, B); t[:B] = rng.integers(0, E, B); r[:B] = rng.integers(0, R, B)
@@ -27,9 +29,14 @@ def rand_batch(rng, E, R, B, n, nr, foreign=0.0):
         if k < n:
             side = rng.random(B) < 0.5
             new = rng.integers(0, E, B)
+            if distinct:
+                old = np.where(side, h[:B], t[:B])
+                new = (old + 1 + rng.integers(0, E - 1, B)) % E
             h[s] = np.where(side, new, h[:B]); t[s] = np.where(side, t[:B], new)
         else:
             r[s] = rng.integers(0, R, B)
+            if distinct:
+                r[s] = (r[:B] + 1 + rng.integers(0, R - 1, B)) % R
     if foreign > 0:  # arbitrary negatives: any slot combination may differ, or none
         m = rng.random(B * N) < foreign
         idx = np.nonzero(m)[0] + B
@@ -39,11 +46,12 @@ def rand_batch(rng, E, R, B, n, nr, foreign=0.0):
     return h, t, r
 
 
-def make_engine(model, E, R, D, n, nr, margin=1.0, opt="SGD", alpha=0.01, params=None, Dr=None):
+def make_engine(model, E, R, D, n, nr, margin=1.0, opt="SGD", alpha=0.01, params=None, Dr=None, use_counts=True):
     """A Config over a dummy dataset (the model ops only need the totals) with given parameters."""
     from openkeonspark_amd.Config import Config
     import openkeonspark_amd as pkg
     con = Config()
+    con.use_counts = use_counts
     con.set_ent_neg_rate(n); con.set_rel_neg_rate(nr); con.set_margin(margin)
     con.set_opt_method(opt); con.set_alpha(alpha)
     if Dr is None:
@@ -130,13 +138,146 @@ def test_training_steps_match_oracle(model, opt):
         assert abs(lg - lo) <= 2e-5 * abs(lo), (step, lg, lo)
         got = con.get_parameters()
         for k in orc.params:
-            # Adam divides by sqrt(v)+eps: gradient rounding differences are amplified where v ~ 0,
-            # so the parameter comparison is on the update scale (alpha), not on 1e-5 of it
-            tol = 2e-5 if opt == "SGD" else 2e-4
-            assert relerr(got[k], orc.params[k]) < tol, (step, k, relerr(got[k], orc.params[k]))
+            # compare the accumulated UPDATE (the parameters' own magnitude would hide it).  Adam is
+            # scale-free in g: where a gradient element nearly cancels, rounding differences are
+            # amplified to a fraction of one step, so Adam is bounded on the step scale alpha.
+            du_o = orc.params[k].astype(np.float64) - params[k]
+            du_g = got[k].astype(np.float64) - params[k]
+            if opt == "SGD":
+                assert np.abs(du_g - du_o).max() <= 1e-4 * np.abs(du_o).max(), (step, k)
+            else:
+                bad = np.abs(du_g - du_o) > 1e-3 * np.abs(du_o).max()
+                assert bad.sum() <= max(3, 2e-3 * bad.size) and np.abs(du_g - du_o).max() <= 4 * alpha, (step, k, bad.sum())
     assert con.global_step == 5
     for g in con.get_gradients().values():
         assert not g.any()  # accumulators are re-zeroed by the update kernels
+
+
+@pytest.fixture(params=["bucket", "sort"])
+def reducer(request):
+    """Both reductions of the sign-count records: LDS buckets (small tables) and sort + segmented sum."""
+    from openkeonspark_amd import _lib
+    L = _lib.lib()
+    L.kge_set_option(b"counts_force_sort", 1 if request.param == "sort" else 0)
+    yield request.param
+    L.kge_set_option(b"counts_force_sort", 0)
+
+
+@pytest.mark.parametrize("D", [16, 50, 100, 200, 512])
+@pytest.mark.parametrize("n,nr,foreign", [(1, 0, 0.0), (25, 0, 0.0), (3, 2, 0.0), (4, 1, 0.3)])
+def test_transe_sign_count_gradient_matches_oracle(D, n, nr, foreign, reducer):
+    """TransE integer sign-count path (int8 records -> sort -> segmented sum -> per-row normalise
+    backward): the gradient it applies, read back as p_before - p_after of an SGD step with lr = 1,
+    against the oracle's dense gradient.  Few rows / many records per row: runs that span chunks,
+    hub rows, and non sampler-shaped negatives (residual path)."""
+    rng = np.random.default_rng(abs(hash((D, n, nr))) % 2**32)
+    E, R, B = (97, 5, 700) if D != 100 else (1500, 9, 700)   # 1500 rows: several rows per LDS bucket
+    params = oracle.init_params(oracle.TRANSE, E, R, D, D, seed=6)
+    for k in params:
+        params[k] = (params[k] * 3).astype(np.float32)
+    orc = oracle.Model("transe", E, R, D, D, margin=0.8, negative_rel=nr, params=params)
+    con = make_engine("transe", E, R, D, n, nr, margin=0.8, opt="SGD", alpha=1.0, params=params)
+    assert con.use_counts
+    bh, bt, br = rand_batch(rng, E, R, B, n, nr, foreign)
+    loss_o, g_o = orc.grad(bh, bt, br, B, n + nr)
+    loss_g = con.train_step(bh, bt, br, None)
+    assert abs(loss_g - loss_o) <= RTOL * abs(loss_o)
+    got = con.get_parameters()
+    for k in g_o:
+        g_g = params[k].astype(np.float64) - got[k].astype(np.float64)
+        # p - 1.0*g is rounded to fp32 at the parameter's magnitude: allow that quantum on top of 1e-5
+        quantum = np.abs(params[k]).max() * 2.0 ** -23
+        assert np.abs(g_g - g_o[k]).max() <= RTOL * np.abs(g_o[k]).max() + quantum, k
+    assert not con._counts.any().item()
+    for g in con.get_gradients().values():
+        assert not g.any()
+
+
+def numpy_sign_counts(params, bh, bt, br, B, N, margin):
+    """Integer sign-count gradient of the TransE loss w.r.t. the NORMALISED rows, straight from the
+    definition (TransE.py:11-15,48-51): rows [0,E) entities, [E,E+R) relations."""
+    ent, rel = params["ent_embeddings"], params["rel_embeddings"]
+    E, D = ent.shape
+    l2 = lambda x: x / np.sqrt(np.maximum((x * x).sum(-1, keepdims=True), 1e-12)).astype(np.float32)
+    en, rn = l2(ent), l2(rel)
+    S = np.zeros((E + rel.shape[0], D), np.int64)
+    e_p = en[bh[:B]] + rn[br[:B]] - en[bt[:B]]
+    p = np.abs(e_p).sum(-1)
+    for k in range(N):
+        sl = slice(B * (k + 1), B * (k + 2))
+        e_k = en[bh[sl]] + rn[br[sl]] - en[bt[sl]]
+        active = (p - np.abs(e_k).sum(-1) + np.float32(margin)) >= 0
+        sp, sk = np.sign(e_p).astype(np.int64), np.sign(e_k).astype(np.int64)
+        for b in np.nonzero(active)[0]:
+            S[bh[b]] += sp[b]; S[E + br[b]] += sp[b]; S[bt[b]] -= sp[b]
+            S[bh[sl][b]] -= sk[b]; S[E + br[sl][b]] -= sk[b]; S[bt[sl][b]] += sk[b]
+    return S
+
+
+@pytest.mark.parametrize("D,n", [(16, 25), (50, 25), (16, 40), (100, 40), (200, 63), (64, 3)])
+def test_transe_sign_counts_are_the_exact_integer_sums(D, n, reducer):
+    """The int32 counts before the per-row finalisation equal the definition's integer sums EXACTLY
+    (multi-round id prefetch when n exceeds the team width, int8 saturation margin at n = 63)."""
+    import torch
+    rng = np.random.default_rng(D * 100 + n)
+    E, R, B = 61, 4, 300
+    params = oracle.init_params(oracle.TRANSE, E, R, D, D, seed=2)
+    bh, bt, br = rand_batch(rng, E, R, B, n, 0, distinct=True)
+    con = make_engine("transe", E, R, D, n, 0, margin=1.0, params=params)
+    dev = torch.from_numpy(np.stack([bh, bt, br]).astype(np.int32)).cuda()
+    con.forward_counts(dev, B, B, B * n)
+    got = con._counts.cpu().numpy().astype(np.int64)
+    want = numpy_sign_counts(params, bh, bt, br, B, n, 1.0)
+    bad_rows = np.nonzero((got != want).any(1))[0]
+    # a hinge within rounding of zero may legitimately flip: allow a couple of rows, not a pattern
+    assert len(bad_rows) <= 2, (len(bad_rows), bad_rows[:10], np.abs(got - want).max())
+    con._counts.zero_()
+
+
+@pytest.mark.parametrize("D,n", [(100, 1), (200, 25)])
+@pytest.mark.parametrize("opt", ["SGD", "Adam"])
+def test_transe_sign_count_training_tracks_oracle(D, n, opt):
+    """Several steps; the comparison is on the UPDATE (p_k - p_0), not on the parameters, whose
+    magnitude would hide it.  Adam is scale-free in g, so elements whose gradient nearly cancels
+    amplify rounding differences: the Adam bound is on the update scale alpha."""
+    rng = np.random.default_rng(23)
+    E, R, B = 300, 7, 512
+    params = oracle.init_params(oracle.TRANSE, E, R, D, D, seed=7)
+    alpha = 0.05 if opt == "SGD" else 0.01
+    orc = oracle.Model("transe", E, R, D, D, margin=1.0, params=params)
+    con = make_engine("transe", E, R, D, n, 0, margin=1.0, opt=opt, alpha=alpha, params=params)
+    for step in range(4):
+        bh, bt, br = rand_batch(rng, E, R, B, n, 0)
+        lo = orc.sgd_step(bh, bt, br, B, n, alpha) if opt == "SGD" else orc.adam_step(bh, bt, br, B, n, alpha)
+        lg = con.train_step(bh, bt, br, None)
+        assert abs(lg - lo) <= 2e-5 * abs(lo), (step, lg, lo)
+    got = con.get_parameters()
+    for k in orc.params:
+        du_o = orc.params[k].astype(np.float64) - params[k]
+        du_g = got[k].astype(np.float64) - params[k]
+        if opt == "SGD":
+            assert np.abs(du_g - du_o).max() <= 1e-4 * np.abs(du_o).max(), k
+        else:
+            # a handful of near-cancelling elements may differ by a fraction of one Adam step
+            bad = np.abs(du_g - du_o) > 1e-3 * np.abs(du_o).max()
+            assert bad.sum() <= max(3, 2e-3 * bad.size) and np.abs(du_g - du_o).max() <= 4 * alpha, (k, bad.sum())
+
+
+def test_transe_generic_path_still_matches_oracle():
+    """use_counts=False keeps the fp32-atomic path (the one data-parallel H/D/R also use) for TransE."""
+    rng = np.random.default_rng(17)
+    E, R, D, B, n = 120, 6, 64, 128, 3
+    params = oracle.init_params(oracle.TRANSE, E, R, D, D, seed=5)
+    orc = oracle.Model("transe", E, R, D, D, params=params)
+    con = make_engine("transe", E, R, D, n, 0, opt="SGD", alpha=0.05, params=params, use_counts=False)
+    assert not con.use_counts
+    for step in range(3):
+        bh, bt, br = rand_batch(rng, E, R, B, n, 0)
+        lo = orc.sgd_step(bh, bt, br, B, n, 0.05)
+        lg = con.train_step(bh, bt, br, None)
+        assert abs(lg - lo) <= 2e-5 * abs(lo)
+    for k in orc.params:
+        assert relerr(con.get_parameters()[k], orc.params[k]) < 2e-5
 
 
 def test_adam_kernel_bitwise_on_identical_gradient():
