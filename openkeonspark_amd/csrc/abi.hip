@@ -200,6 +200,8 @@ const char *kge_version(void) { return "kge_mi355 0.1 (gfx950)"; }
 int kge_set_option(const char *name, INT value) {
     std::string n = name ? name : "";
     if (n == "counts_force_sort") { engine().counts_force_sort = value != 0; return KGE_OK; }
+    if (n == "emit_variant") { engine().emit_variant = (int)value; return KGE_OK; }
+    if (n == "emit_debug") { engine().emit_debug = (int)value; return KGE_OK; }
     return fail(KGE_ERR_BAD_ARG, "kge_set_option: unknown option " + n);
 }
 

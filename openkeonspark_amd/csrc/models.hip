@@ -45,6 +45,8 @@ struct FbArgs {
     // kernel walks group_list[0 .. *group_count) instead of 0 .. n_pos
     int32_t *group_list;
     int32_t *group_count;
+    int debug;  // diagnosis only
+    const float *inv_norm;  // [E+R] 1/|row| of ent_embeddings then rel_embeddings, refreshed per step (vectorised emit)
 };
 
 // One entity side (h or t slot) of a scored triple: raw row(s), projected+normalised vector.
@@ -360,7 +362,10 @@ __device__ __forceinline__ void store_record(const FbArgs &a, int lane, long lon
 
 // team-uniform broadcast of lane `src` (index inside the team)
 template <int L>
-__device__ __forceinline__ int team_bcast(int v, int src) { return __shfl(v, src, L); }
+__device__ __forceinline__ int team_bcast(int v, int src) {
+    if constexpr (L == 64) return __builtin_amdgcn_readlane(v, src);  // wave == team: uniform result in an SGPR
+    else return __shfl(v, src, L);
+}
 
 template <int L, int C>
 __global__ __launch_bounds__(256) void transe_emit_kernel(FbArgs a) {
@@ -528,6 +533,224 @@ __global__ __launch_bounds__(256) void transe_emit_kernel(FbArgs a) {
     }
 }
 
+// ---- vectorised, instruction-lean variant (D % 4 == 0) ----------------------------------------------
+// Profiling the first version showed the emit kernel ISSUE-bound (~300 VALU instructions per negative:
+// three-way selects per element, compare/select sign extraction, IEEE sqrt+divide, byte-wise adds),
+// not memory-bound: skipping its stores or gathering only hot rows did not change its time.  This
+// version keeps the per-negative work to ~50 instructions:
+//   * 1/|row| comes from a per-row table refreshed once per step (row_inv_norm_kernel): no sum of
+//     squares, no rsqrt, and only ONE team reduction per negative (the L1 score);
+//   * e = f*x + B with B = (r^-t^), (h^+r^) or (h^-t^) precomputed per group and f = +-1/|x|:
+//     one fma per element;
+//   * sign(e) = med3(bits(e), -1, 1) on the integer pattern of the float (one instruction/element;
+//     -0.0 would read as -1, which can only arise from exact cancellation of negative zeros);
+//   * the integer gradient vectors are packed int16 pairs (v_pk_add_i16), bytes only when stored;
+//   * one global_load_dwordx4 per row chunk.  Record dword w = lane + L*q holds elements 4w..4w+3
+//     ("natural" layout, flagged to the reducers).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int sign_of_bits(float e) {
+    int r;
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(__builtin_bit_cast(int, e)));
+    return r;
+}
+__device__ __forceinline__ s16x2 pack16(int lo, int hi) { s16x2 r; r.x = (short)lo; r.y = (short)hi; return r; }
+// the four low bytes of two int16 pairs -> one record dword
+__device__ __forceinline__ uint32_t bytes_of(s16x2 lo, s16x2 hi) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
+}
+
+template <int L, int Q, int K, int WPE>
+__global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
+    constexpr int TEAMS = 256 / L;
+    __shared__ float red[TEAMS];
+    const int lane = threadIdx.x % L;
+    const int team_in_block = threadIdx.x / L;
+    const int D = a.D;
+    const float *inv_ent = a.inv_norm, *inv_rel = a.inv_norm + a.ent_total;
+    bool valid[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) valid[q] = 4 * (lane + L * q) < D;
+    auto load4 = [&](const float *__restrict__ tab, long long row, float4 (&x)[Q]) {
+        const float *p = tab + row * D;
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+            x[q] = valid[q] ? *reinterpret_cast<const float4 *>(p + 4 * (lane + L * q)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float lsum = 0.f;
+    for (long long b = (long long)blockIdx.x * TEAMS + team_in_block; b < a.n_pos; b += (long long)gridDim.x * TEAMS) {
+        const int h = a.bh[b], t = a.bt[b], r = a.br[b];
+        // ---- negatives' ids: one per lane (first round), classified once ----
+        int my_code = 0, my_row = 0;
+        float my_f = 0.f;
+        float bad = 0.f;
+        for (int k = lane; k < (int)a.n_neg; k += L) {
+            const long long j = b + (long long)(k + 1) * a.stride;
+            const int nh = a.bh[j], nt = a.bt[j], nr = a.br[j];
+            const NegClass nc = classify_negative<KGE_TRANSE>(h, t, r, nh, nt, nr, a.negative_rel);
+            if (!nc.fast) bad = 1.f;
+            if (k < L) {   // keep round 0 (the only round when n_neg <= L)
+                my_code = !nc.same_h ? 0 : (!nc.same_t ? 1 : 2);
+                my_row = !nc.same_h ? nh : (!nc.same_t ? nt : nr);
+            }
+        }
+        if (team_sum<L>(bad) != 0.f) {   // not sampler-shaped: the whole group goes to the exact fp32 kernel
+            if (lane == 0) {
+                for (long long sl = 0; sl < 3 + a.n_neg; sl++) a.dst[sl * a.n_pos + b] = -1;
+                a.group_list[atomicAdd(a.group_count, 1)] = (int32_t)b;
+            }
+            continue;
+        }
+        // f = +1/|x| for a new head or relation vector, -1/|x| for a new tail (e = f*x + B)
+        if (lane < (int)a.n_neg) { const float iv = my_code == 2 ? inv_rel[my_row] : inv_ent[my_row]; my_f = my_code == 1 ? -iv : iv; }
+        // ---- the positive: B0 = r^-t^, B1 = h^+r^, B2 = h^-t^ ----
+        float4 B0[Q], B1[Q], B2[Q];
+        float p;
+        s16x2 sp_lo[Q], sp_hi[Q];
+        {
+            float4 hn[Q], tn[Q], rn[Q];
+            load4(a.ent, h, hn); load4(a.ent, t, tn); load4(a.rel, r, rn);
+            const float ih = inv_ent[h], it = inv_ent[t], ir = inv_rel[r];
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const float4 H = make_float4(hn[q].x * ih, hn[q].y * ih, hn[q].z * ih, hn[q].w * ih);
+                const float4 T = make_float4(tn[q].x * it, tn[q].y * it, tn[q].z * it, tn[q].w * it);
+                const float4 R = make_float4(rn[q].x * ir, rn[q].y * ir, rn[q].z * ir, rn[q].w * ir);
+                B0[q] = make_float4(R.x - T.x, R.y - T.y, R.z - T.z, R.w - T.w);
+                B1[q] = make_float4(H.x + R.x, H.y + R.y, H.z + R.z, H.w + R.w);
+                B2[q] = make_float4(H.x - T.x, H.y - T.y, H.z - T.z, H.w - T.w);
+                const float e0 = H.x + R.x - T.x, e1 = H.y + R.y - T.y, e2 = H.z + R.z - T.z, e3 = H.w + R.w - T.w;
+                acc += fabsf(e0) + fabsf(e1) + fabsf(e2) + fabsf(e3);
+                sp_lo[q] = pack16(sign_of_bits(e0), sign_of_bits(e1));
+                sp_hi[q] = pack16(sign_of_bits(e2), sign_of_bits(e3));
+            }
+            p = team_sum<L>(acc);
+        }
+        s16x2 Ah_lo[Q], Ah_hi[Q], At_lo[Q], At_hi[Q], Ar_lo[Q], Ar_hi[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) { Ah_lo[q] = 0; Ah_hi[q] = 0; At_lo[q] = 0; At_hi[q] = 0; Ar_lo[q] = 0; Ar_hi[q] = 0; }
+        int cnt = 0;
+        for (int k0 = 0; k0 < (int)a.n_neg; k0 += L) {
+            if (k0 > 0) {   // later rounds (n_neg > L): fetch and classify this round's ids
+                const int my_k = k0 + lane;
+                my_code = 0; my_row = 0; my_f = 0.f;
+                if (my_k < (int)a.n_neg) {
+                    const long long j = b + (long long)(my_k + 1) * a.stride;
+                    const int nh = a.bh[j], nt = a.bt[j], nr = a.br[j];
+                    const NegClass nc = classify_negative<KGE_TRANSE>(h, t, r, nh, nt, nr, a.negative_rel);
+                    my_code = !nc.same_h ? 0 : (!nc.same_t ? 1 : 2);
+                    my_row = !nc.same_h ? nh : (!nc.same_t ? nt : nr);
+                    const float iv = my_code == 2 ? inv_rel[my_row] : inv_ent[my_row];
+                    my_f = my_code == 1 ? -iv : iv;
+                }
+            }
+            const int in_round = min(L, (int)a.n_neg - k0);
+            int my_dst = -1;
+            for (int kk = 0; kk < in_round; kk += K) {
+                int code[K], row[K];
+                float f[K];
+                float4 x[K][Q];
+#pragma unroll
+                for (int u = 0; u < K; u++) {
+                    const int src = min(kk + u, in_round - 1);
+                    code[u] = team_bcast<L>(my_code, src);
+                    row[u] = team_bcast<L>(my_row, src);
+                    f[u] = __builtin_bit_cast(float, team_bcast<L>(__builtin_bit_cast(int, my_f), src));
+                }
+#pragma unroll
+                for (int u = 0; u < K; u++) load4(code[u] == 2 ? a.rel : a.ent, row[u], x[u]);  // K gathers in flight
+                float sc[K];
+#pragma unroll
+                for (int u = 0; u < K; u++) {
+                    float acc = 0.f;
+                    auto apply = [&](const float4 (&Bs)[Q]) {
+#pragma unroll
+                        for (int q = 0; q < Q; q++) {
+                            x[u][q].x = fmaf(f[u], x[u][q].x, Bs[q].x); x[u][q].y = fmaf(f[u], x[u][q].y, Bs[q].y);
+                            x[u][q].z = fmaf(f[u], x[u][q].z, Bs[q].z); x[u][q].w = fmaf(f[u], x[u][q].w, Bs[q].w);
+                            acc += fabsf(x[u][q].x) + fabsf(x[u][q].y) + fabsf(x[u][q].z) + fabsf(x[u][q].w);
+                        }
+                    };
+                    if (code[u] == 0) apply(B0); else if (code[u] == 1) apply(B1); else apply(B2);
+                    sc[u] = acc;
+                }
+#pragma unroll
+                for (int u = 0; u < K; u++) sc[u] = team_sum<L>(sc[u]);
+#pragma unroll
+                for (int u = 0; u < K; u++) {
+                    if (kk + u >= in_round) continue;
+                    const float v = p - sc[u] + a.margin;
+                    if (v >= 0.f) {
+                        cnt++; lsum += v;
+                        const long long m = (long long)(3 + k0 + kk + u) * a.n_pos + b;
+                        uint32_t rec[Q];
+#pragma unroll
+                        for (int q = 0; q < Q; q++) {
+                            const s16x2 s_lo = pack16(sign_of_bits(x[u][q].x), sign_of_bits(x[u][q].y));
+                            const s16x2 s_hi = pack16(sign_of_bits(x[u][q].z), sign_of_bits(x[u][q].w));
+                            if (code[u] == 0) {         // new head: dL/dx^ = -s ; kept t gets +s, r gets -s
+                                rec[q] = bytes_of(-s_lo, -s_hi);
+                                At_lo[q] += s_lo; At_hi[q] += s_hi; Ar_lo[q] -= s_lo; Ar_hi[q] -= s_hi;
+                            } else if (code[u] == 1) {  // new tail: +s ; kept h gets -s, r gets -s
+                                rec[q] = bytes_of(s_lo, s_hi);
+                                Ah_lo[q] -= s_lo; Ah_hi[q] -= s_hi; Ar_lo[q] -= s_lo; Ar_hi[q] -= s_hi;
+                            } else {                    // new relation vector: -s ; h gets -s, t gets +s
+                                rec[q] = bytes_of(-s_lo, -s_hi);
+                                Ah_lo[q] -= s_lo; Ah_hi[q] -= s_hi; At_lo[q] += s_lo; At_hi[q] += s_hi;
+                            }
+                        }
+                        store_record<L, Q>(a, lane, m, rec);
+                        if (lane == kk + u) my_dst = code[u] == 2 ? a.ent_total + row[u] : row[u];
+                    }
+                }
+            }
+            // destinations of this round's negatives: one store instruction for the whole round
+            if (k0 + lane < (int)a.n_neg) a.dst[(long long)(3 + k0 + lane) * a.n_pos + b] = my_dst;
+        }
+        if (cnt > 0) {
+            uint32_t rh[Q], rt[Q], rr[Q];
+            const s16x2 c2 = pack16(cnt, cnt);
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const s16x2 v_lo = sp_lo[q] * c2, v_hi = sp_hi[q] * c2;
+                rh[q] = bytes_of(Ah_lo[q] + v_lo, Ah_hi[q] + v_hi);
+                rt[q] = bytes_of(At_lo[q] - v_lo, At_hi[q] - v_hi);
+                rr[q] = bytes_of(Ar_lo[q] + v_lo, Ar_hi[q] + v_hi);
+            }
+            store_record<L, Q>(a, lane, b, rh);
+            store_record<L, Q>(a, lane, a.n_pos + b, rt);
+            store_record<L, Q>(a, lane, 2 * a.n_pos + b, rr);
+        }
+        if (lane == 0) {
+            a.dst[b] = cnt > 0 ? (int32_t)h : -1;
+            a.dst[a.n_pos + b] = cnt > 0 ? (int32_t)t : -1;
+            a.dst[2 * a.n_pos + b] = cnt > 0 ? (int32_t)(a.ent_total + r) : -1;
+        }
+    }
+    if (lane == 0) red[team_in_block] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < TEAMS; i++) s += red[i];
+        a.loss_partials[blockIdx.x] = s;
+    }
+}
+
+// 1/max(|row|,1e-6): tf.nn.l2_normalize's rsqrt(max(sum x^2, 1e-12)) for every row of the two tables
+__global__ __launch_bounds__(256) void row_inv_norm_kernel(const float *__restrict__ ent, const float *__restrict__ rel,
+                                                           long long E, long long R, int D, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < E + R; row += (long long)gridDim.x * 4) {
+        const float *p = row < E ? ent + row * D : rel + (row - E) * D;
+        float s = 0.f;
+        for (int e = lane; e < D; e += 64) s += p[e] * p[e];
+        s = team_sum<64>(s);
+        if (lane == 0) out[row] = 1.0f / sqrtf(s >= 1e-12f ? s : 1e-12f);
+    }
+}
+
 constexpr int kDeferBlocks = 128;
 
 template <int L, int C>
@@ -536,9 +759,18 @@ static void launch_emit(const FbArgs &a, float *d_loss, hipStream_t stream) {
     long long blocks = (a.n_pos + TEAMS - 1) / TEAMS;
     if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
     if (blocks < 1) blocks = 1;
-    FbArgs e = a;
-    e.group_list = a.group_list;  // emit APPENDS deferred groups here
-    hipLaunchKernelGGL((transe_emit_kernel<L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, e);
+    if (a.D % 4 == 0) {
+        long long nb = (a.ent_total + a.rel_total + 3) / 4;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.ent, a.rel, (long long)a.ent_total,
+                           (long long)a.rel_total, a.D, const_cast<float *>(a.inv_norm));
+        const int variant = engine().emit_variant;
+        if (variant == 1) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 4>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        else if (variant == 2) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 8, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        else if (variant == 3) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 2, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    } else
+        hipLaunchKernelGGL((transe_emit_kernel<L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
     // groups with non sampler-shaped negatives: exact fp32 path into the residual accumulators
     FbArgs d = a;
     d.loss_partials = a.loss_partials + blocks;
@@ -548,7 +780,8 @@ static void launch_emit(const FbArgs &a, float *d_loss, hipStream_t stream) {
 
 // team shape used for dimension D (shared with transe_counts.hip through these two helpers)
 void transe_team_shape(int D, int &L, int &C) {
-    if (D <= 16) { L = 16; C = 1; } else if (D <= 32) { L = 16; C = 2; } else if (D <= 64) { L = 16; C = 4; }
+    if (D % 4 == 0 && D <= 64) { L = 16; C = 4; }  // vectorised kernel: one float4 per lane
+    else if (D <= 16) { L = 16; C = 1; } else if (D <= 32) { L = 16; C = 2; } else if (D <= 64) { L = 16; C = 4; }
     else if (D <= 128) { L = 32; C = 4; } else if (D <= 256) { L = 64; C = 4; } else if (D <= 512) { L = 64; C = 8; }
     else { L = 64; C = 16; }
 }
@@ -575,7 +808,17 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
         int rc = hip_check(hipMemsetAsync(defer_count, 0, sizeof(int32_t), stream), "zero deferred count");
         if (rc) return rc;
     }
+    static float *inv_norm = nullptr;
+    static int64_t inv_cap = 0;
+    if (m.ent_total + m.rel_total > inv_cap) {
+        if (inv_norm) (void)hipFree(inv_norm);
+        inv_norm = nullptr;
+        int rc = hip_check(hipMalloc(&inv_norm, sizeof(float) * (size_t)(m.ent_total + m.rel_total)), "alloc row inverse norms");
+        if (rc) return rc;
+        inv_cap = m.ent_total + m.rel_total;
+    }
     FbArgs a = {};
+    a.inv_norm = inv_norm;
     a.group_list = defer_list; a.group_count = defer_count;
     a.ent = ent; a.rel = rel; a.g_ent = resid_ent; a.g_rel = resid_rel;
     a.bh = d_h; a.bt = d_t; a.br = d_r;
@@ -584,8 +827,10 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
     a.loss_partials = e.dev.loss_partials;
     a.negative_rel = m.negative_rel;
     a.rec = rec; a.dst = dst; a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total; a.krel = krel;
+    a.debug = e.emit_debug;
     const int D = a.D;
-    if (D <= 16) launch_emit<16, 1>(a, d_loss, stream);
+    if (D % 4 == 0 && D <= 64) launch_emit<16, 4>(a, d_loss, stream);
+    else if (D <= 16) launch_emit<16, 1>(a, d_loss, stream);
     else if (D <= 32) launch_emit<16, 2>(a, d_loss, stream);
     else if (D <= 64) launch_emit<16, 4>(a, d_loss, stream);
     else if (D <= 128) launch_emit<32, 4>(a, d_loss, stream);

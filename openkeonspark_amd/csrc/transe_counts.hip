@@ -99,12 +99,17 @@ __global__ void count_valid_kernel(const int32_t *__restrict__ sorted, int M, in
 
 constexpr int CHUNK = 64;
 
-template <int L, int C>
+// element held in accumulator c of `lane`: strided layout (dword-per-lane kernels) or natural layout
+// (vectorised kernels: record dword w = lane + L*(c/4) holds elements 4w .. 4w+3)
+template <int L, bool NAT>
+__device__ __forceinline__ int elem_of(int lane, int c) { return NAT ? 4 * (lane + L * (c / 4)) + (c % 4) : lane + L * c; }
+
+template <int L, int C, bool NAT>
 __device__ __forceinline__ void flush_run(int32_t *__restrict__ S, int D, int lane, long long row, const int (&acc)[C], bool atomic) {
     int32_t *p = S + row * D;
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        const int e = lane + L * c;
+        const int e = elem_of<L, NAT>(lane, c);
         if (e < D) {
             if (atomic) { if (acc[c] != 0) atomicAdd(p + e, acc[c]); }
             else p[e] = acc[c];
@@ -112,7 +117,7 @@ __device__ __forceinline__ void flush_run(int32_t *__restrict__ S, int D, int la
     }
 }
 
-template <int L, int C>
+template <int L, int C, bool NAT>
 __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict__ rec, const int32_t *__restrict__ keys,
                                                      const int32_t *__restrict__ ids, const int32_t *__restrict__ n_valid_p,
                                                      int32_t *__restrict__ S, int D) {
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict_
         for (int u = 0; u < U; u++) {
             if (k[u] < 0) break;
             if (k[u] != cur) {
-                flush_run<L, C>(S, D, lane, cur, acc, first_run);
+                flush_run<L, C, NAT>(S, D, lane, cur, acc, first_run);
 #pragma unroll
                 for (int c = 0; c < C; c++) acc[c] = 0;
                 cur = k[u];
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict_
                 }
         }
     }
-    flush_run<L, C>(S, D, lane, cur, acc, true);
+    flush_run<L, C, NAT>(S, D, lane, cur, acc, true);
 }
 
 
@@ -254,61 +259,41 @@ __global__ __launch_bounds__(256) void bkt_scatter_kernel(const int32_t *__restr
     }
 }
 
-template <int L, int Q>
-__global__ __launch_bounds__(512) void bkt_reduce_kernel(const uint32_t *__restrict__ rec, const int2 *__restrict__ pairs,
-                                                         const int32_t *__restrict__ bucket_start, int rpb, int rows, int D,
-                                                         int32_t *__restrict__ S) {
-    extern __shared__ int lds_S[];
-    constexpr int RD = L * Q;
+// second level: counting sort of one bucket's pairs by destination row (rpb rows, LDS histogram), so
+// that the whole list is row-sorted and the register-accumulating segsum_kernel can consume it.
+// (An LDS-image reduction with ds_add per element was tried first: correct, but bound by the LDS
+// atomic rate -- 3.8 M wave-level ds_add per step -- at 230 us; registers + sorted runs take ~60.)
+__global__ __launch_bounds__(256) void bkt_sort_kernel(const int2 *__restrict__ pairs, const int32_t *__restrict__ bucket_start,
+                                                       int rpb, int rows, int32_t *__restrict__ out_keys,
+                                                       int32_t *__restrict__ out_ids) {
+    extern __shared__ int lds_h[];   // [rpb] histogram, then running offsets
     const int b = blockIdx.x;
     const int row0 = b * rpb;
-    const int nrows = min(rpb, rows - row0);
-    if (nrows <= 0) return;
-    for (int i = threadIdx.x; i < nrows * D; i += blockDim.x) lds_S[i] = 0;
-    __syncthreads();
+    if (row0 >= rows) return;
     const int start = bucket_start[b], end = bucket_start[b + 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    constexpr int RPW = RD >= 64 ? 1 : 64 / RD;      // records handled side by side by one wave
-    constexpr int WPL = RD >= 64 ? RD / 64 : 1;      // dwords per lane per record
-    const int sub = RD >= 64 ? 0 : lane / RD;
-    const int w0 = RD >= 64 ? lane : lane % RD;
-    constexpr int U = 8;                              // record loads in flight per wave
-    for (int i0 = start + wave * (RPW * U); i0 < end; i0 += nwaves * RPW * U) {
-        // loads are unconditional (index clamped) and issued in two batches -- all pairs, then all
-        // records -- so 8 independent requests are in flight per wave instead of 16 serialised ones
-        int2 pr[U];
-        int drow[U];
-        uint32_t w[U][WPL];
+    for (int i = threadIdx.x; i < rpb; i += 256) lds_h[i] = 0;
+    __syncthreads();
+    for (int i = start + threadIdx.x; i < end; i += 256) atomicAdd(&lds_h[pairs[i].y - row0], 1);
+    __syncthreads();
+    if (threadIdx.x < 64) {   // exclusive scan of rpb counters by one wave
+        int carry = 0;
+        for (int base = 0; base < rpb; base += 64) {
+            const int i = base + threadIdx.x;
+            const int v = i < rpb ? lds_h[i] : 0;
+            int incl = v;
 #pragma unroll
-        for (int u = 0; u < U; u++) pr[u] = pairs[min(i0 + u * RPW + sub, end - 1)];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t *p = rec + (long long)pr[u].x * RD;
-#pragma unroll
-            for (int x = 0; x < WPL; x++) w[u][x] = p[w0 + 64 * x];
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) drow[u] = (i0 + u * RPW + sub < end) ? pr[u].y - row0 : -1;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (drow[u] < 0) continue;
-            int *Srow = lds_S + drow[u] * D;
-#pragma unroll
-            for (int x = 0; x < WPL; x++) {
-                const int wd = w0 + 64 * x;
-                const int q = wd / L, l = wd - q * L;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int e = l + L * (4 * q + j);
-                    const int v = (int)(int8_t)(w[u][x] >> (8 * j));
-                    if (e < D && v != 0) atomicAdd(&Srow[e], v);
-                }
-            }
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if ((int)threadIdx.x >= off) incl += t; }
+            if (i < rpb) lds_h[i] = carry + incl - v;
+            carry += __shfl(incl, 63);
         }
     }
     __syncthreads();
-    int32_t *out = S + (long long)row0 * D;
-    for (int i = threadIdx.x; i < nrows * D; i += blockDim.x) out[i] = lds_S[i];
+    for (int i = start + threadIdx.x; i < end; i += 256) {
+        const int2 pr = pairs[i];
+        const int pos = start + atomicAdd(&lds_h[pr.y - row0], 1);
+        out_keys[pos] = pr.y;
+        out_ids[pos] = pr.x;
+    }
 }
 
 // stage 3.  optimizer: 0 = SGD (lr), 1 = Adam (lr = lr_t)
@@ -379,7 +364,8 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
 }
 
 #define KGE_SHAPE_DISPATCH(D, CALL)                                      \
-    if (D <= 16) { CALL(16, 1); } else if (D <= 32) { CALL(16, 2); }     \
+    if (D % 4 == 0 && D <= 64) { CALL(16, 4); }                          \
+    else if (D <= 16) { CALL(16, 1); } else if (D <= 32) { CALL(16, 2); } \
     else if (D <= 64) { CALL(16, 4); } else if (D <= 128) { CALL(32, 4); } \
     else if (D <= 256) { CALL(64, 4); } else if (D <= 512) { CALL(64, 8); } \
     else { CALL(64, 16); }
@@ -421,10 +407,10 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
                             1, d_loss, stream);
     if (rc) return rc;
     const int D = m->ent_dim;
+    const bool nat = D % 4 == 0;   // the vectorised emit kernel writes records in natural element order
     const int rpb = (rows + NB - 1) / NB;
-    const size_t lds_bytes = (size_t)rpb * D * sizeof(int);
-    if (lds_bytes <= 64 * 1024 && !engine().counts_force_sort) {
-        // ---- LDS-bucket reduce (small row spaces) ----
+    if (rpb <= 8192 && !engine().counts_force_sort) {
+        // ---- two-level counting sort (hand-written) + segmented sum: row spaces up to NB*8192 rows ----
         const int n_tiles = (int)((M + BTILE - 1) / BTILE);
         if (!g_c.bucket_start) {
             if ((rc = regrow(g_c.bucket_start, NB + 2, "counts bucket_start"))) return rc;
@@ -436,11 +422,20 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
         hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals);
         hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(1024), 0, stream, totals, g_c.bucket_start, cursor);
         hipLaunchKernelGGL(bkt_scatter_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, cursor, pairs);
-#define KGE_BKT(LL, CC)                                                                                                  \
-        hipLaunchKernelGGL((bkt_reduce_kernel<LL, (CC + 3) / 4>), dim3(NB), dim3(512), lds_bytes, stream, g_c.rec, pairs, \
-                           g_c.bucket_start, rpb, rows, D, d_counts);
-        KGE_SHAPE_DISPATCH(D, KGE_BKT)
-#undef KGE_BKT
+        hipLaunchKernelGGL(bkt_sort_kernel, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
+                           g_c.dst_sorted, g_c.ids_sorted);
+        const int32_t *n_valid_p = g_c.bucket_start + NB;   // start of the trash bucket == number of live records
+#define KGE_SEG2(LL, CC)                                                                                              \
+    {                                                                                                                 \
+        const long long chunks = (M + CHUNK - 1) / CHUNK;                                                             \
+        const long long nb = (chunks + (256 / LL) - 1) / (256 / LL);                                                  \
+        if (nat) hipLaunchKernelGGL((segsum_kernel<LL, CC, true>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,  \
+                                    g_c.dst_sorted, g_c.ids_sorted, n_valid_p, d_counts, D);                          \
+        else hipLaunchKernelGGL((segsum_kernel<LL, CC, false>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,     \
+                                g_c.dst_sorted, g_c.ids_sorted, n_valid_p, d_counts, D);                              \
+    }
+        KGE_SHAPE_DISPATCH(D, KGE_SEG2)
+#undef KGE_SEG2
         return hip_check(hipGetLastError(), "counts bucket reduce launch");
     }
     // ---- general path: sort + segmented sum (large row spaces) ----
@@ -456,8 +451,10 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
     {                                                                                                                 \
         const long long chunks = (M + CHUNK - 1) / CHUNK;                                                             \
         const long long nb = (chunks + (256 / LL) - 1) / (256 / LL);                                                  \
-        hipLaunchKernelGGL((segsum_kernel<LL, CC>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec, g_c.dst_sorted, \
-                           g_c.ids_sorted, g_c.n_valid, d_counts, D);                                                 \
+        if (nat) hipLaunchKernelGGL((segsum_kernel<LL, CC, true>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,  \
+                                    g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, d_counts, D);                        \
+        else hipLaunchKernelGGL((segsum_kernel<LL, CC, false>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,     \
+                                g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, d_counts, D);                            \
     }
     KGE_SHAPE_DISPATCH(D, KGE_SEG)
 #undef KGE_SEG
