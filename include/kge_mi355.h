@@ -82,9 +82,13 @@ void kge_clear_error(void);
 int kge_device_available(void);
 const char *kge_version(void);
 
-/* engine options (testing / tuning).  "counts_force_sort": 1 = always reduce sign-count records with
- * the sort + segmented-sum kernels, 0 (default) = use the LDS-bucket reduction when the table fits */
+/* engine options (testing / measurement).
+ *   "counts_force_sort": 1 = order the sign-count records with rocPRIM's radix sort instead of the
+ *                        hand-written two-level counting sort (default 0)
+ *   "time_emit":         1 = bracket the TransE emit kernel with HIP events on its launch stream */
 int kge_set_option(const char *name, INT value);
+/* elapsed time of the most recent launch of a timed kernel; name = "transe_emit" (needs time_emit) */
+int kge_last_kernel_ms(const char *name, float *ms);
 
 /* Same as importTrainFiles but from arrays already in memory (h,t,r in FILE ORDER, duplicates
  * kept; new_batch_total as batch2id.txt's first line, 0 = not incremental).  Restates

@@ -200,9 +200,17 @@ const char *kge_version(void) { return "kge_mi355 0.1 (gfx950)"; }
 int kge_set_option(const char *name, INT value) {
     std::string n = name ? name : "";
     if (n == "counts_force_sort") { engine().counts_force_sort = value != 0; return KGE_OK; }
-    if (n == "emit_variant") { engine().emit_variant = (int)value; return KGE_OK; }
-    if (n == "emit_debug") { engine().emit_debug = (int)value; return KGE_OK; }
+    if (n == "time_emit") { engine().time_emit = value != 0; return KGE_OK; }
     return fail(KGE_ERR_BAD_ARG, "kge_set_option: unknown option " + n);
+}
+
+int kge_last_kernel_ms(const char *name, float *ms) {
+    Engine &e = engine();
+    std::string n = name ? name : "";
+    if (n != "transe_emit" || !ms) return fail(KGE_ERR_BAD_ARG, "kge_last_kernel_ms: unknown kernel " + n);
+    if (!e.ev_emit0) return fail(KGE_ERR_BAD_ARG, "kge_last_kernel_ms: enable option time_emit and run a step first");
+    if (hip_check(hipEventSynchronize(e.ev_emit1), "event sync")) return KGE_ERR_NO_DEVICE;
+    return hip_check(hipEventElapsedTime(ms, e.ev_emit0, e.ev_emit1), "event elapsed");
 }
 
 int kge_import_train_arrays(INT ent_total, INT rel_total, INT n, const INT *h, const INT *t, const INT *r,

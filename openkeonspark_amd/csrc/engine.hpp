@@ -47,8 +47,8 @@ struct Engine {
     DeviceIndex dev;
     std::string last_error;
     int device_state = 0;  // 0 unknown, 1 ok, -1 none
-    int emit_debug = 0;
-    int emit_variant = 0;       // tuning hook for the TransE emit kernel (negatives in flight / occupancy)
+    int time_emit = 0;          // record HIP events around the TransE emit kernel (kge_last_kernel_ms)
+    hipEvent_t ev_emit0 = nullptr, ev_emit1 = nullptr;
     int counts_force_sort = 0;  // test hook: take the sort+segsum reduction even for small tables
 };
 

@@ -764,11 +764,13 @@ static void launch_emit(const FbArgs &a, float *d_loss, hipStream_t stream) {
         if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.ent, a.rel, (long long)a.ent_total,
                            (long long)a.rel_total, a.D, const_cast<float *>(a.inv_norm));
-        const int variant = engine().emit_variant;
-        if (variant == 1) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 4>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        else if (variant == 2) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 8, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        else if (variant == 3) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 2, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        Engine &eng = engine();
+        if (eng.time_emit) {   // HIP events around THE kernel, on its launch stream (bench.py roofline)
+            if (!eng.ev_emit0) { (void)hipEventCreate(&eng.ev_emit0); (void)hipEventCreate(&eng.ev_emit1); }
+            (void)hipEventRecord(eng.ev_emit0, stream);
+        }
+        hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        if (eng.time_emit) (void)hipEventRecord(eng.ev_emit1, stream);
     } else
         hipLaunchKernelGGL((transe_emit_kernel<L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
     // groups with non sampler-shaped negatives: exact fp32 path into the residual accumulators
@@ -827,7 +829,6 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
     a.loss_partials = e.dev.loss_partials;
     a.negative_rel = m.negative_rel;
     a.rec = rec; a.dst = dst; a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total; a.krel = krel;
-    a.debug = e.emit_debug;
     const int D = a.D;
     if (D % 4 == 0 && D <= 64) launch_emit<16, 4>(a, d_loss, stream);
     else if (D <= 16) launch_emit<16, 1>(a, d_loss, stream);
