@@ -669,3 +669,183 @@ int orc_max_threads(void) {
     return 1;
 #endif
 }
+
+/* ==========================================================================================
+ * Link-prediction evaluation inputs and ranker.  PINNED against the
+ * reference build (tests/golden/lp_*.npz).
+ * ======================================================================================== */
+typedef struct OrcEval {
+    i64 ent_total, rel_total, test_total, valid_total, triple_total;
+    OrcTriple *test_list;    /* sorted by (r,h,t)  (Reader.h:256, Triple.h:30-32) */
+    OrcTriple *triple_list;  /* test + train + valid, sorted by (h,r,t) (Reader.h:255) */
+    /* type constraints (Reader.h:302-365): per relation sorted candidate heads / tails */
+    i64 *head_lef, *head_rig, *tail_lef, *tail_rig, *head_type, *tail_type;
+    /* ontology (Reader.h:376-449): per entity sorted super / sub classes */
+    i64 *sup_lef, *sup_rig, *sub_lef, *sub_rig, *sup_type, *sub_type;
+} OrcEval;
+
+static int cmp_rht(const void *pa, const void *pb) { /* Triple.h:30-32 cmp_rel2 */
+    const OrcTriple *a = pa, *b = pb;
+    if (a->r != b->r) return a->r < b->r ? -1 : 1;
+    if (a->h != b->h) return a->h < b->h ? -1 : 1;
+    if (a->t != b->t) return a->t < b->t ? -1 : 1;
+    return 0;
+}
+static int cmp_i64(const void *a, const void *b) { i64 x = *(const i64 *)a, y = *(const i64 *)b; return (x > y) - (x < y); }
+
+static i64 *read_all_longs(const char *path, i64 *n_out) {
+    FILE *f = fopen(path, "r");
+    if (!f) return NULL;
+    i64 cap = 1024, n = 0, v;
+    i64 *a = malloc(sizeof(i64) * (size_t)cap);
+    while (fscanf(f, "%ld", &v) == 1) { if (n == cap) { cap *= 2; a = realloc(a, sizeof(i64) * (size_t)cap); } a[n++] = v; }
+    fclose(f);
+    *n_out = n;
+    return a;
+}
+
+/* Reader.h:186-292 */
+OrcEval *orc_eval_load(const char *dir) {
+    char path[4096];
+    OrcEval *ev = calloc(1, sizeof(OrcEval));
+    i64 n;
+    i64 *a;
+    snprintf(path, sizeof path, "%srelation2id.txt", dir); a = read_all_longs(path, &n); if (!a) return NULL; ev->rel_total = a[0]; free(a);
+    snprintf(path, sizeof path, "%sentity2id.txt", dir); a = read_all_longs(path, &n); if (!a) return NULL; ev->ent_total = a[0]; free(a);
+    i64 nt, ntr, nv;
+    snprintf(path, sizeof path, "%stest2id.txt", dir); i64 *te = read_all_longs(path, &nt); if (!te) return NULL;
+    snprintf(path, sizeof path, "%strain2id.txt", dir); i64 *tr = read_all_longs(path, &ntr); if (!tr) return NULL;
+    snprintf(path, sizeof path, "%svalid2id.txt", dir); i64 *va = read_all_longs(path, &nv); if (!va) return NULL;
+    i64 T = te[0], Tr = tr[0], V = va[0];
+    ev->test_total = T; ev->valid_total = V; ev->triple_total = T + Tr + V;
+    ev->test_list = calloc((size_t)(T > 0 ? T : 1), sizeof(OrcTriple));
+    ev->triple_list = calloc((size_t)(ev->triple_total > 0 ? ev->triple_total : 1), sizeof(OrcTriple));
+    i64 k = 0;
+    for (i64 i = 0; i < T; i++) { OrcTriple x = { te[1 + 3 * i], te[3 + 3 * i], te[2 + 3 * i] }; ev->test_list[i] = x; ev->triple_list[k++] = x; }
+    for (i64 i = 0; i < Tr; i++) { OrcTriple x = { tr[1 + 3 * i], tr[3 + 3 * i], tr[2 + 3 * i] }; ev->triple_list[k++] = x; }
+    for (i64 i = 0; i < V; i++) { OrcTriple x = { va[1 + 3 * i], va[3 + 3 * i], va[2 + 3 * i] }; ev->triple_list[k++] = x; }
+    free(te); free(tr); free(va);
+    qsort(ev->triple_list, (size_t)ev->triple_total, sizeof(OrcTriple), cmp_hrt);
+    qsort(ev->test_list, (size_t)T, sizeof(OrcTriple), cmp_rht);
+    /* type_constrain.txt (Reader.h:302-365): count, then per relation "rel n heads..." and "rel n tails..." */
+    snprintf(path, sizeof path, "%stype_constrain.txt", dir);
+    a = read_all_longs(path, &n);
+    if (a) {
+        i64 R = ev->rel_total;
+        ev->head_lef = calloc((size_t)R, sizeof(i64)); ev->head_rig = calloc((size_t)R, sizeof(i64));
+        ev->tail_lef = calloc((size_t)R, sizeof(i64)); ev->tail_rig = calloc((size_t)R, sizeof(i64));
+        ev->head_type = malloc(sizeof(i64) * (size_t)(n + 1)); ev->tail_type = malloc(sizeof(i64) * (size_t)(n + 1));
+        i64 p = 1, nh = 0, ntl = 0;
+        for (i64 i = 0; i < R && p + 1 < n; i++) {
+            i64 rel = a[p], tot = a[p + 1]; p += 2;
+            ev->head_lef[rel] = nh;
+            for (i64 j = 0; j < tot; j++) ev->head_type[nh++] = a[p++];
+            ev->head_rig[rel] = nh;
+            qsort(ev->head_type + ev->head_lef[rel], (size_t)tot, sizeof(i64), cmp_i64);
+            rel = a[p]; tot = a[p + 1]; p += 2;
+            ev->tail_lef[rel] = ntl;
+            for (i64 j = 0; j < tot; j++) ev->tail_type[ntl++] = a[p++];
+            ev->tail_rig[rel] = ntl;
+            qsort(ev->tail_type + ev->tail_lef[rel], (size_t)tot, sizeof(i64), cmp_i64);
+        }
+        free(a);
+    }
+    /* ontology_constrain.txt (Reader.h:376-449): count, then per entity "ent n supers..." and "ent n subs..." */
+    snprintf(path, sizeof path, "%sontology_constrain.txt", dir);
+    a = read_all_longs(path, &n);
+    if (a) {
+        i64 E = ev->ent_total;
+        ev->sup_lef = calloc((size_t)E, sizeof(i64)); ev->sup_rig = calloc((size_t)E, sizeof(i64));
+        ev->sub_lef = calloc((size_t)E, sizeof(i64)); ev->sub_rig = calloc((size_t)E, sizeof(i64));
+        ev->sup_type = malloc(sizeof(i64) * (size_t)(n + 1)); ev->sub_type = malloc(sizeof(i64) * (size_t)(n + 1));
+        i64 tot_ont = a[0], p = 1, ns = 0, nb = 0;
+        for (i64 i = 0; i < tot_ont; i++) {
+            i64 ent = a[p], tot = a[p + 1]; p += 2;
+            ev->sup_lef[ent] = ns;
+            for (i64 j = 0; j < tot; j++) ev->sup_type[ns++] = a[p++];
+            ev->sup_rig[ent] = ns;
+            qsort(ev->sup_type + ev->sup_lef[ent], (size_t)tot, sizeof(i64), cmp_i64);
+            ent = a[p]; tot = a[p + 1]; p += 2;
+            ev->sub_lef[ent] = nb;
+            for (i64 j = 0; j < tot; j++) ev->sub_type[nb++] = a[p++];
+            ev->sub_rig[ent] = nb;
+            qsort(ev->sub_type + ev->sub_lef[ent], (size_t)tot, sizeof(i64), cmp_i64);
+        }
+        free(a);
+    }
+    return ev;
+}
+
+i64 orc_eval_test_total(const OrcEval *ev) { return ev->test_total; }
+i64 orc_eval_valid_total(const OrcEval *ev) { return ev->valid_total; }
+i64 orc_eval_triple_total(const OrcEval *ev) { return ev->triple_total; }
+void orc_eval_test_triple(const OrcEval *ev, i64 i, i64 *htr) { htr[0] = ev->test_list[i].h; htr[1] = ev->test_list[i].t; htr[2] = ev->test_list[i].r; }
+
+/* Corrupt.h:104-115 */
+static int eval_find(const OrcEval *ev, i64 h, i64 t, i64 r) {
+    i64 lef = 0, rig = ev->triple_total - 1;
+    while (lef + 1 < rig) {
+        i64 mid = (lef + rig) >> 1;
+        const OrcTriple *m = &ev->triple_list[mid];
+        if (m->h < h || (m->h == h && m->r < r) || (m->h == h && m->r == r && m->t < t)) lef = mid; else rig = mid;
+    }
+    const OrcTriple *a = &ev->triple_list[lef], *b = &ev->triple_list[rig];
+    if (a->h == h && a->r == r && a->t == t) return 1;
+    if (b->h == h && b->r == r && b->t == t) return 1;
+    return 0;
+}
+
+/* ontology classes of the four arg-mins w.r.t. the expected entity (Test.h:113-135 / :226-248):
+ * 0 correct, 1 a superclass (generalisation), 2 a subclass (specialisation), 3 anything else.
+ * The reference walks ONE pair of cursors over the sorted super/sub lists for all four values in
+ * turn and never rewinds them, so a later arg-min smaller than an earlier one can be missed --
+ * reproduced by keeping the cursors across the four lookups. */
+static void onto_classes(const OrcEval *ev, i64 expected, i64 *arr /* [4] in, [4] out */) {
+    i64 lsup = ev->sup_lef ? ev->sup_lef[expected] : 0, rsup = ev->sup_lef ? ev->sup_rig[expected] : 0;
+    i64 lsub = ev->sub_lef ? ev->sub_lef[expected] : 0, rsub = ev->sub_lef ? ev->sub_rig[expected] : 0;
+    for (int i = 0; i < 4; i++) {
+        i64 v = arr[i];
+        if (v == expected) { arr[i] = 0; continue; }
+        while (lsup < rsup && ev->sup_type[lsup] < v) lsup++;
+        if (lsup < rsup && ev->sup_type[lsup] == v) { arr[i] = 1; continue; }
+        while (lsub < rsub && ev->sub_type[lsub] < v) lsub++;
+        if (lsub < rsub && ev->sub_type[lsub] == v) { arr[i] = 2; continue; }
+        arr[i] = 3;
+    }
+}
+
+/* Test.h:31-136 (head) and :141-249 (tail).  out[0..3] = number of candidates scoring strictly lower
+ * (raw, filtered, type-constrained, both); out[4..7] = ontology class of the four arg-mins.  The
+ * head version's filtered arg-min is updated OUTSIDE the `if (not _find)` (missing braces,
+ * Test.h:69-74) -- reproduced. */
+void orc_test_rank(const OrcEval *ev, i64 index, const float *con, int head, i64 *out) {
+    i64 h = ev->test_list[index].h, t = ev->test_list[index].t, r = ev->test_list[index].r;
+    i64 target = head ? h : t;
+    float minimal = con[target];
+    i64 s = 0, fs = 0, cs = 0, fcs = 0;
+    i64 mn = target, fmn = target, cmn = target, fcmn = target;
+    float mv = minimal, fmv = minimal, cmv = minimal, fcmv = minimal;
+    i64 lef = 0, rig = 0;
+    const i64 *types = NULL;
+    if (ev->head_lef) { lef = head ? ev->head_lef[r] : ev->tail_lef[r]; rig = head ? ev->head_rig[r] : ev->tail_rig[r]; types = head ? ev->head_type : ev->tail_type; }
+    for (i64 j = 0; j < ev->ent_total; j++) {
+        if (j == target) continue;
+        float value = con[j];
+        int known = head ? eval_find(ev, j, t, r) : eval_find(ev, h, j, r);
+        if (value < minimal) {
+            s++;
+            if (value < mv) { mv = value; mn = j; }
+            if (!known) fs++;
+            if (head ? 1 : !known) { if (value < fmv) { fmv = value; fmn = j; } }
+        }
+        while (lef < rig && types[lef] < j) lef++;
+        if (lef < rig && types[lef] == j && value < minimal) {
+            cs++;
+            if (value < cmv) { cmv = value; cmn = j; }
+            if (!known) { fcs++; if (value < fcmv) { fcmv = value; fcmn = j; } }
+        }
+    }
+    out[0] = s; out[1] = fs; out[2] = cs; out[3] = fcs;
+    out[4] = mn; out[5] = fmn; out[6] = cmn; out[7] = fcmn;
+    onto_classes(ev, target, out + 4);
+}

@@ -66,6 +66,14 @@ def lib():
         L.orc_sgd_apply_dense.argtypes = [vp, vp, i64, f32]
         L.orc_adam_apply_dense.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32]
         L.orc_predict.argtypes = [vp, vp, vp, vp, i64, vp]
+        L.orc_eval_load.restype = vp
+        L.orc_eval_load.argtypes = [ctypes.c_char_p]
+        for name in ("test_total", "valid_total", "triple_total"):
+            fn = getattr(L, "orc_eval_" + name)
+            fn.restype = i64
+            fn.argtypes = [vp]
+        L.orc_eval_test_triple.argtypes = [vp, i64, vp]
+        L.orc_test_rank.argtypes = [vp, i64, vp, ci, vp]
         L.orc_max_threads.restype = ci
         L.orc_libc_rand_init.argtypes = [vp]
         L.orc_libc_rand_next.restype = ctypes.c_int32
@@ -287,6 +295,34 @@ class Model:
         return out
 
 
+class Eval:
+    """Link-prediction oracle: importTestFiles / importTypeFiles / importOntologyFiles
+    (Reader.h:186-449) + testHead / testTail (Test.h:31-249)."""
+
+    def __init__(self, path):
+        if not path.endswith("/"):
+            path += "/"
+        self._h = lib().orc_eval_load(path.encode())
+        if not self._h:
+            raise FileNotFoundError(path)
+        self.testTotal = lib().orc_eval_test_total(self._h)
+        self.validTotal = lib().orc_eval_valid_total(self._h)
+        self.tripleTotal = lib().orc_eval_triple_total(self._h)
+
+    def test_triple(self, i):
+        """(h, t, r) of the i-th test triple in the reference's (r,h,t)-sorted order (Reader.h:256)."""
+        out = np.zeros(3, np.int64)
+        lib().orc_eval_test_triple(self._h, i, _p(out))
+        return tuple(int(x) for x in out)
+
+    def rank(self, i, scores, head):
+        """testHead (head=True) / testTail: 8 int64 as the reference returns them."""
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        out = np.zeros(8, np.int64)
+        lib().orc_test_rank(self._h, i, _p(scores), 1 if head else 0, _p(out))
+        return out
+
+
 class ReferenceSampler:
     """The reference's own Base.so (compiled by oracle/Makefile into oracle/_ref/), driven the way
     Config.py:30-31,160-170,347 drives it.  Process-global state: ONE dataset per process."""
@@ -339,3 +375,29 @@ class ReferenceSampler:
         y = np.zeros(n, np.float32)
         self.L.sampling(_p(h), _p(t), _p(r), _p(y), B, neg, negrel)
         return h, t, r, y
+
+    # --- link prediction, driven as Config.py:74-80,34-39 and distribute_training.py:465-475 do ---
+    def init_link_prediction(self):
+        L = self.L
+        L.importTestFiles(); L.importTypeFiles(); L.importOntologyFiles()
+        for fn in ("getTestTotal", "getValidTotal", "getTripleTotal"):
+            getattr(L, fn).restype = ctypes.c_int64
+        L.getTailBatch.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.getHeadBatch.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.testTail.argtypes = [ctypes.c_int64, ctypes.c_void_p]
+        L.testTail.restype = ctypes.POINTER(ctypes.c_int64 * 8)
+        L.testHead.argtypes = [ctypes.c_int64, ctypes.c_void_p]
+        L.testHead.restype = ctypes.POINTER(ctypes.c_int64 * 8)
+        self.testTotal = L.getTestTotal()
+        self.validTotal = L.getValidTotal()
+        self.tripleTotal = L.getTripleTotal()
+
+    def batch(self, i, head):
+        h = np.zeros(self.entTotal, np.int64); t = np.zeros(self.entTotal, np.int64); r = np.zeros(self.entTotal, np.int64)
+        (self.L.getHeadBatch if head else self.L.getTailBatch)(i, _p(h), _p(t), _p(r))
+        return h, t, r
+
+    def rank(self, i, scores, head):
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        res = (self.L.testHead if head else self.L.testTail)(i, _p(scores))
+        return np.array(list(res.contents), dtype=np.int64)

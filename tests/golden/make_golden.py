@@ -53,6 +53,65 @@ def make_tiny_graphs():
     write_openke_dir(os.path.join(HERE, "kg_incr"), 60, 4, hi, ti, ri, new_batch_total=37)
 
 
+def write_eval_files(kg, E, R, seed):
+    """test2id / valid2id / type_constrain / ontology_constrain in the formats Reader.h:186-449 reads
+    (made up here; the reference ships no data)."""
+    rng = np.random.default_rng(seed)
+    d = os.path.join(HERE, kg)
+    train = np.loadtxt(os.path.join(d, "train2id.txt"), skiprows=1, dtype=np.int64)
+    def some(n):
+        rows = train[rng.integers(0, len(train), n)].copy()           # start from known triples ...
+        flip = rng.random(n) < 0.7
+        rows[flip, 1] = rng.integers(0, E, int(flip.sum()))          # ... and corrupt most tails
+        return rows
+    test, valid = some(40), some(30)
+    for name, arr in (("test2id.txt", test), ("valid2id.txt", valid)):
+        with open(os.path.join(d, name), "w") as f:
+            f.write("%d\n" % len(arr))
+            np.savetxt(f, arr, fmt="%d")
+    allt = np.concatenate([train, test, valid])
+    with open(os.path.join(d, "type_constrain.txt"), "w") as f:
+        f.write("%d\n" % R)
+        for r in range(R):
+            m = allt[:, 2] == r
+            heads = sorted(set(allt[m, 0].tolist()) | set(rng.integers(0, E, 3).tolist()))
+            tails = sorted(set(allt[m, 1].tolist()) | set(rng.integers(0, E, 3).tolist()))
+            rng.shuffle(heads); rng.shuffle(tails)                    # the loader sorts them itself
+            f.write("%d\t%d%s\n" % (r, len(heads), "".join("\t%d" % x for x in heads)))
+            f.write("%d\t%d%s\n" % (r, len(tails), "".join("\t%d" % x for x in tails)))
+    ents = sorted(rng.choice(E, size=min(E, 25), replace=False).tolist())
+    with open(os.path.join(d, "ontology_constrain.txt"), "w") as f:
+        f.write("%d\n" % len(ents))
+        for e in ents:
+            sup = rng.choice(E, size=int(rng.integers(0, 6)), replace=False).tolist()
+            sub = rng.choice(E, size=int(rng.integers(0, 6)), replace=False).tolist()
+            f.write("%d\t%d%s\n" % (e, len(sup), "".join("\t%d" % x for x in sup)))
+            f.write("%d\t%d%s\n" % (e, len(sub), "".join("\t%d" % x for x in sub)))
+
+
+def lp_worker(kg_dir, out_path, n_triples, seed):
+    """Reference testHead / testTail on seeded score vectors (quantised so that ties occur)."""
+    from oracle.oracle import ReferenceSampler
+    ref = ReferenceSampler(kg_dir, work_threads=1, bern=0)
+    ref.init_link_prediction()
+    rng = np.random.default_rng(seed)
+    E = ref.entTotal
+    n = min(n_triples, ref.testTotal)
+    scores = np.round(rng.standard_normal((n, 2, E)).astype(np.float32) * 2, 1)
+    out = np.zeros((n, 2, 8), np.int64)
+    triples = np.zeros((n, 3), np.int64)
+    for i in range(n):
+        hb = ref.batch(i, head=False)
+        triples[i] = (hb[0][0], None or 0, hb[2][0])
+        tb = ref.batch(i, head=True)
+        triples[i] = (hb[0][0], tb[1][0], hb[2][0])                  # (h, t, r) of the i-th sorted test triple
+        # make the target's own score mid-range so that some candidates beat it
+        out[i, 0] = ref.rank(i, scores[i, 0], head=True)
+        out[i, 1] = ref.rank(i, scores[i, 1], head=False)
+    np.savez_compressed(out_path, totals=np.array([ref.testTotal, ref.validTotal, ref.tripleTotal], np.int64),
+                        triples=triples, scores=scores, out=out)
+
+
 def worker(kg_dir, W, bern, out_path, shapes, calls):
     from oracle.oracle import ReferenceSampler
     ref = ReferenceSampler(kg_dir, work_threads=W, bern=bern)
@@ -94,6 +153,10 @@ def main():
         a = json.loads(sys.argv[2])
         worker(a["kg"], a["W"], a["bern"], a["out"], a["shapes"], a["calls"])
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--lp":
+        a = json.loads(sys.argv[2])
+        lp_worker(a["kg"], a["out"], a["n"], a["seed"])
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--digest":
         a = json.loads(sys.argv[2])
         digest_worker(a["kg"], a["W"], a["bern"], a["B"], a["n"], a["nr"], a["calls"], a["out"])
@@ -108,6 +171,13 @@ def main():
                 subprocess.check_call([sys.executable, __file__, "--worker", json.dumps(arg)],
                                       stdout=subprocess.DEVNULL)
                 print("wrote", os.path.relpath(out, ROOT))
+    # link-prediction inputs + reference testHead/testTail outputs
+    for kg, (E, R) in {"kg_tiny": (30, 6), "kg_small": (1000, 20)}.items():
+        write_eval_files(kg, E, R, seed=len(kg))
+        out = os.path.join(HERE, "lp_%s.npz" % kg)
+        arg = dict(kg=os.path.join(HERE, kg) + "/", out=out, n=30, seed=5)
+        subprocess.check_call([sys.executable, __file__, "--lp", json.dumps(arg)], stdout=subprocess.DEVNULL)
+        print("wrote", os.path.relpath(out, ROOT))
     # FB15k-237-shaped synthetic graph: generated (not committed), digests committed
     from openkeonspark_amd.synthetic import make_dataset, FB15K237
     fb = make_dataset("/tmp/okes_fb15k237_shaped", FB15K237)
