@@ -62,6 +62,27 @@ INT getValidTotal(void);          /* replaces base/Setting.h:100-103 */
  * Bit-identical to the reference for the same workThreads / bern / call history. */
 void sampling(INT *batch_h, INT *batch_t, INT *batch_r, REAL *batch_y, INT batchSize, INT negRate, INT negRelRate);
 
+/* Evaluation subset of Base.so (link prediction) */
+void importTestFiles(void);      /* replaces base/Reader.h:185-292: test2id / valid2id + the sorted union used by the filter */
+void importTypeFiles(void);      /* replaces base/Reader.h:301-365: type_constrain.txt */
+void importOntologyFiles(void);  /* replaces base/Reader.h:375-449: ontology_constrain.txt */
+void getHeadBatch(INT index, INT *ph, INT *pt, INT *pr);  /* replaces base/Test.h:10-17 */
+void getTailBatch(INT index, INT *ph, INT *pt, INT *pr);  /* replaces base/Test.h:19-26 */
+/* replace base/Test.h:30-136 and :140-249.  `con` = HOST score vector of all entities; returns 8 INT:
+ * [0..3] candidates scoring strictly lower (raw, filtered, type-constrained, both), [4..7] ontology
+ * class of the four arg-mins.  The pointer addresses a library-owned slot reused after 64 calls (the
+ * reference leaks a `new INT[8]` per call). */
+INT *testHead(INT index, REAL *con);
+INT *testTail(INT index, REAL *con);
+/* Triple classification (base/Test.h:262-444): exported so that Config.py:41-51 binds, NOT built yet
+ *  -- each call records an error retrievable with kge_last_error. */
+void getTestBatch(INT *ph, INT *pt, INT *pr, INT *nh, INT *nt, INT *nr);
+void getValidBatch(INT *ph, INT *pt, INT *pr, INT *nh, INT *nt, INT *nr);
+void getBestThreshold(REAL *relThresh, REAL *score_pos, REAL *score_neg);
+void test_triple_classification(REAL *relThresh, REAL *score_pos, REAL *score_neg, REAL *acc);
+INT get_n_interval(INT r, REAL *score_pos, REAL *score_neg);
+INT *get_TPFP(INT r, REAL *score_pos, REAL *score_neg, REAL *threshold, REAL *unused);
+
 /* ------------------------------------------------------------------------------------------
  * (2) Engine entry points
  * ---------------------------------------------------------------------------------------- */
@@ -182,6 +203,13 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
                               int32_t *d_counts, float *d_resid_ent, float *d_resid_rel, float *d_loss, void *stream);
 int kge_transe_apply_counts(float *d_p, float *d_m, float *d_v, int32_t *d_counts, float *d_resid, int64_t rows, int32_t dim,
                             INT denom, int32_t adam, float lr, float beta1, float beta2, float eps, void *stream);
+
+/* Device-native link prediction for test triples [first, first+count) (replaces the loop
+ * distribute_training.py:465-590: getTailBatch -> sess.run(predict) -> testTail, and the head side when
+ * test_head != 0).  h_out (HOST) receives count x 2 x 8 int64: [i][0] testTail's 8-vector, [i][1]
+ * testHead's (zeros if test_head == 0).  Needs importTestFiles (+ Type / Ontology files if present). */
+int kge_link_prediction(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES], INT first, INT count,
+                        INT test_head, int64_t *h_out, void *stream);
 
 /* predict op: score n triples.  TransE: mean over the dimension (TransE.py:58); others: sum
  * (TransH.py:82, TransR.py:87 with predict_r[0]'s matrix for all, TransD.py:98). */

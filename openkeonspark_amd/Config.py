@@ -87,9 +87,25 @@ class Config(object):
                 self.bt = self.lib.getBatchTotal()
                 self.set_mini_batch()
                 self._alloc_batch_buffers()
-            if self.test_link_prediction or self.test_triple_classification or self.valid_triple_classification:
-                # evaluation inputs (Reader.h:186-449) are outside the hot path built so far
-                pass
+            if self.test_link_prediction:
+                self.init_link_prediction()
+            # triple-classification inputs (Test.h:266-444) are not built yet
+
+    def init_link_prediction(self):
+        r'''
+        import essential files for link prediction (Config.py:74-80); type / ontology constraints are
+        optional here (the reference crashes without them)
+        '''
+        path = self.in_path if self.in_path.endswith("/") else self.in_path + "/"
+        self.lib.kge_clear_error()
+        self.lib.importTestFiles()
+        if os.path.exists(path + "type_constrain.txt"):
+            self.lib.importTypeFiles()
+        if os.path.exists(path + "ontology_constrain.txt"):
+            self.lib.importOntologyFiles()
+        _lib.raise_if_error(self.lib)
+        self.testTotal = self.lib.getTestTotal()
+        self.validTotal = self.lib.getValidTotal()
 
     def init_from_arrays(self, ent_total, rel_total, h, t, r, new_batch_total=0):
         """Same as init() with the training triples (file order) given as arrays instead of files."""
@@ -399,6 +415,37 @@ class Config(object):
                                         dev[2].data_ptr(), host.shape[1], out.data_ptr(), self._stream()), self.lib)
         self.trainModel.predict = out
         return out.cpu().numpy()
+
+    def link_prediction(self, first=0, count=None, test_head=True):
+        """Rank every test triple in [first, first+count) on the device (replaces the per-triple loop of
+        distribute_training.py:465-590).  Returns (raw int64 [count,2,8] as testTail/testHead give them,
+        metrics dict with the reference's accumulator names normalised by the number of triples, the way
+        main_spark.py:430-448 reduces them: r_* = tail prediction, l_* = head prediction)."""
+        if count is None:
+            count = self.lib.getTestTotal() - first
+        out = np.zeros((count, 2, 8), dtype=np.int64)
+        _lib.check(self.lib.kge_link_prediction(ctypes.byref(self._desc), self._tab_ptrs, first, count,
+                                                1 if test_head else 0, out.ctypes.data, self._stream()), self.lib)
+        d = {}
+        n = float(max(count, 1))
+        for side, p in ((0, "r"), (1, "l")):
+            if side == 1 and not test_head:
+                continue
+            raw, filt, raw_c, filt_c = (out[:, side, i] for i in range(4))
+            for name, cnt in (("", raw), ("_filter", filt)):
+                sfx = name
+                d[p + sfx + "_tot"] = float((cnt < 10).sum()) / n          # Hits@10
+                d[p + "3" + sfx + "_tot"] = float((cnt < 3).sum()) / n      # Hits@3
+                d[p + "1" + sfx + "_tot"] = float((cnt < 1).sum()) / n      # Hits@1
+                d[p + sfx + "_rank"] = float((1 + cnt).sum()) / n           # MR
+                d[p + sfx + "_reci_rank"] = float((1.0 / (1 + cnt)).sum()) / n  # MRR
+            for name, cnt in (("", raw_c), ("_filter", filt_c)):
+                d[p + name + "_tot_constrain"] = float((cnt < 10).sum()) / n
+                d[p + "3" + name + "_tot_constrain"] = float((cnt < 3).sum()) / n
+                d[p + "1" + name + "_tot_constrain"] = float((cnt < 1).sum()) / n
+                d[p + name + "_rank_constrain"] = float((1 + cnt).sum()) / n
+                d[p + name + "_reci_rank_constrain"] = float((1.0 / (1 + cnt)).sum()) / n
+        return out, d
 
     # ------------------------------------------------------------------------------------------
     # parameters by the reference's variable names (Config.py:378-421)

@@ -38,6 +38,14 @@ def _declare(L):
                "getBatchTotal", "getTestTotal", "getValidTotal"):
         getattr(L, fn).restype = i64
     L.sampling.argtypes = [vp, vp, vp, vp, i64, i64, i64]
+    # evaluation subset, declared as Config.py:34-39 declares it
+    L.getTailBatch.argtypes = [i64, vp, vp, vp]
+    L.getHeadBatch.argtypes = [i64, vp, vp, vp]
+    L.testTail.argtypes = [i64, vp]
+    L.testTail.restype = ctypes.POINTER(ctypes.c_int64 * 8)
+    L.testHead.argtypes = [i64, vp]
+    L.testHead.restype = ctypes.POINTER(ctypes.c_int64 * 8)
+    L.kge_link_prediction.argtypes = [ctypes.POINTER(ModelDesc), ctypes.POINTER(vp), i64, i64, i64, vp, vp]
     # (2) engine
     L.kge_last_error.restype = ctypes.c_size_t
     L.kge_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]

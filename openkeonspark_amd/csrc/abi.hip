@@ -152,12 +152,13 @@ void importTrainFiles(void) {
 
 INT getEntityTotal(void) { return engine().index.ent_total; }
 INT getRelationTotal(void) { return engine().index.rel_total; }
-INT getTripleTotal(void) { return 0; }  // set by importTestFiles in the reference (evaluation, out of scope)
+INT kge_eval_test_total(void); INT kge_eval_valid_total(void); INT kge_eval_triple_total(void);
+INT getTripleTotal(void) { return kge_eval_triple_total(); }  // set by importTestFiles (Reader.h:231)
 INT getTrainTotal(void) { return engine().index.train_uniq; }
 INT getTrainTotal_(void) { return engine().index.train_dup; }
 INT getBatchTotal(void) { return engine().index.new_batch; }
-INT getTestTotal(void) { return 0; }
-INT getValidTotal(void) { return 0; }
+INT getTestTotal(void) { return kge_eval_test_total(); }
+INT getValidTotal(void) { return kge_eval_valid_total(); }
 
 void sampling(INT *batch_h, INT *batch_t, INT *batch_r, REAL *batch_y, INT batchSize, INT negRate, INT negRelRate) {
     Engine &e = engine();

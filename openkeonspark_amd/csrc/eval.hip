@@ -1,0 +1,414 @@
+// Link-prediction evaluation: the inputs of base/Reader.h:186-449 and the
+// ranker of base/Test.h:11-249, with the Base.so entry points kept (importTestFiles, importTypeFiles,
+// importOntologyFiles, getHeadBatch, getTailBatch, testHead, testTail) and a device-native batch
+// entry (kge_link_prediction) that never moves the E-long score vectors over PCIe.
+//
+// Ranker on the device: one workgroup per (test triple, side).  Every thread walks candidates
+// j = tid, tid+256, ...; a candidate scoring strictly lower than the expected entity bumps the raw
+// count, the filtered count unless (j,r,t)/(h,r,j) is a known triple (binary search in the
+// (h,r,t)-sorted union of train+valid+test, Corrupt.h:104-115), and the type-constrained counts when
+// j is in the relation's sorted head/tail type list.  The four arg-mins are lexicographic minima
+// over (score, j) -- the sequential loop's strict `<` keeps the first (smallest j) minimum -- and
+// their ontology classes are resolved by one thread with the reference's non-rewinding cursors.
+#include <algorithm>
+#include <cstring>
+
+#include "engine.hpp"
+
+namespace kge {
+
+struct EvalHost {
+    bool loaded = false, types = false, onto = false;
+    int64_t test_total = 0, valid_total = 0, triple_total = 0;
+    std::vector<Int4> test;         // (h,t,r,0) sorted by (r,h,t)   Reader.h:256
+    std::vector<Int4> all;          // (h,r,t,0) sorted by (h,r,t)   Reader.h:255
+    std::vector<int32_t> head_lef, head_rig, tail_lef, tail_rig, head_type, tail_type;
+    std::vector<int32_t> sup_lef, sup_rig, sub_lef, sub_rig, sup_type, sub_type;
+};
+
+struct EvalDev {
+    bool uploaded = false;
+    int4 *test = nullptr, *all = nullptr;
+    int32_t *head_lef = nullptr, *head_rig = nullptr, *tail_lef = nullptr, *tail_rig = nullptr, *head_type = nullptr, *tail_type = nullptr;
+    int32_t *sup_lef = nullptr, *sup_rig = nullptr, *sub_lef = nullptr, *sub_rig = nullptr, *sup_type = nullptr, *sub_type = nullptr;
+    float *scores = nullptr;      // staging for testHead/testTail and kge_link_prediction
+    int64_t scores_cap = 0;
+    int32_t *cand = nullptr;      // 3 * cap candidate ids
+    long long *out = nullptr;     // 8 * requests
+    int64_t out_cap = 0;
+};
+
+static EvalHost g_eh;
+static EvalDev g_ed;
+
+template <typename T, typename V>
+static int up(T *&dst, const std::vector<V> &src, const char *what) {
+    static_assert(sizeof(T) == sizeof(V), "size mismatch");
+    if (dst) { (void)hipFree(dst); dst = nullptr; }
+    int rc = hip_check(hipMalloc(&dst, sizeof(T) * (src.size() ? src.size() : 1)), what);
+    if (rc) return rc;
+    if (!src.empty()) rc = hip_check(hipMemcpy(dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice), what);
+    return rc;
+}
+
+static int ensure_eval_device() {
+    if (!g_eh.loaded) return fail(KGE_ERR_NO_DATASET, "importTestFiles has not been called");
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "no usable HIP device: the ranker has no CPU fallback");
+    if (g_ed.uploaded) return KGE_OK;
+    int rc;
+    const int64_t E = engine().index.ent_total, R = engine().index.rel_total;
+    if (g_eh.head_lef.empty()) { g_eh.head_lef.assign(R, 0); g_eh.head_rig.assign(R, 0); g_eh.tail_lef.assign(R, 0); g_eh.tail_rig.assign(R, 0); }
+    if (g_eh.sup_lef.empty()) { g_eh.sup_lef.assign(E, 0); g_eh.sup_rig.assign(E, 0); g_eh.sub_lef.assign(E, 0); g_eh.sub_rig.assign(E, 0); }
+    if ((rc = up(g_ed.test, g_eh.test, "upload test"))) return rc;
+    if ((rc = up(g_ed.all, g_eh.all, "upload triples"))) return rc;
+    if ((rc = up(g_ed.head_lef, g_eh.head_lef, "upload types"))) return rc;
+    if ((rc = up(g_ed.head_rig, g_eh.head_rig, "upload types"))) return rc;
+    if ((rc = up(g_ed.tail_lef, g_eh.tail_lef, "upload types"))) return rc;
+    if ((rc = up(g_ed.tail_rig, g_eh.tail_rig, "upload types"))) return rc;
+    if ((rc = up(g_ed.head_type, g_eh.head_type, "upload types"))) return rc;
+    if ((rc = up(g_ed.tail_type, g_eh.tail_type, "upload types"))) return rc;
+    if ((rc = up(g_ed.sup_lef, g_eh.sup_lef, "upload ontology"))) return rc;
+    if ((rc = up(g_ed.sup_rig, g_eh.sup_rig, "upload ontology"))) return rc;
+    if ((rc = up(g_ed.sub_lef, g_eh.sub_lef, "upload ontology"))) return rc;
+    if ((rc = up(g_ed.sub_rig, g_eh.sub_rig, "upload ontology"))) return rc;
+    if ((rc = up(g_ed.sup_type, g_eh.sup_type, "upload ontology"))) return rc;
+    if ((rc = up(g_ed.sub_type, g_eh.sub_type, "upload ontology"))) return rc;
+    g_ed.uploaded = true;
+    return KGE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct RankArgs {
+    const float *scores;     // [n_req][E]
+    const int4 *test, *all;
+    long long n_all;
+    const int32_t *head_lef, *head_rig, *tail_lef, *tail_rig, *head_type, *tail_type;
+    const int32_t *sup_lef, *sup_rig, *sub_lef, *sub_rig, *sup_type, *sub_type;
+    const int32_t *req_index;  // [n_req] test triple index
+    const int32_t *req_head;   // [n_req] 1 = replace head, 0 = replace tail
+    long long *out;            // [n_req][8]
+    int E;
+};
+
+// Corrupt.h:104-115
+__device__ __forceinline__ bool known_triple(const int4 *__restrict__ all, long long n, int h, int t, int r) {
+    long long lef = 0, rig = n - 1;
+    while (lef + 1 < rig) {
+        const long long mid = (lef + rig) >> 1;
+        const int4 m = all[mid];  // (h, r, t)
+        if (m.x < h || (m.x == h && m.y < r) || (m.x == h && m.y == r && m.z < t)) lef = mid; else rig = mid;
+    }
+    const int4 a = all[lef], b = all[rig];
+    return (a.x == h && a.y == r && a.z == t) || (b.x == h && b.y == r && b.z == t);
+}
+
+struct MinPair { float v; int j; };
+__device__ __forceinline__ void take(MinPair &a, float v, int j) { if (v < a.v || (v == a.v && j < a.j)) { a.v = v; a.j = j; } }
+
+__global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
+    const int req = blockIdx.x;
+    const float *con = a.scores + (long long)req * a.E;
+    const int4 tt = a.test[a.req_index[req]];  // (h, t, r)
+    const bool head = a.req_head[req] != 0;
+    const int h = tt.x, t = tt.y, r = tt.z;
+    const int target = head ? h : t;
+    const float minimal = con[target];
+    const int lef = head ? a.head_lef[r] : a.tail_lef[r], rig = head ? a.head_rig[r] : a.tail_rig[r];
+    const int32_t *types = head ? a.head_type : a.tail_type;
+    long long c[4] = {0, 0, 0, 0};
+    // arg-min candidates start at (minimal, target); a candidate must be STRICTLY lower to replace it
+    MinPair m[4];
+    for (int i = 0; i < 4; i++) { m[i].v = minimal; m[i].j = 0x7fffffff; }
+    for (int j = threadIdx.x; j < a.E; j += 256) {
+        if (j == target) continue;
+        const float value = con[j];
+        if (!(value < minimal)) continue;
+        const bool known = head ? known_triple(a.all, a.n_all, j, t, r) : known_triple(a.all, a.n_all, h, j, r);
+        bool typed = false;
+        {   // lower_bound in the relation's sorted type list
+            int lo = lef, hi = rig;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (types[mid] < j) lo = mid + 1; else hi = mid; }
+            typed = lo < rig && types[lo] == j;
+        }
+        c[0]++; take(m[0], value, j);
+        if (!known) c[1]++;
+        if (head || !known) take(m[1], value, j);   // Test.h:69-74: the head version updates this arg-min outside the filter
+        if (typed) { c[2]++; take(m[2], value, j); if (!known) { c[3]++; take(m[3], value, j); } }
+    }
+    __shared__ long long sc[4][256];
+    __shared__ float sv[4][256];
+    __shared__ int sj[4][256];
+    for (int i = 0; i < 4; i++) { sc[i][threadIdx.x] = c[i]; sv[i][threadIdx.x] = m[i].v; sj[i][threadIdx.x] = m[i].j; }
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            for (int i = 0; i < 4; i++) {
+                sc[i][threadIdx.x] += sc[i][threadIdx.x + w];
+                MinPair x = {sv[i][threadIdx.x], sj[i][threadIdx.x]};
+                take(x, sv[i][threadIdx.x + w], sj[i][threadIdx.x + w]);
+                sv[i][threadIdx.x] = x.v; sj[i][threadIdx.x] = x.j;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        long long *o = a.out + (long long)req * 8;
+        int arg[4];
+        for (int i = 0; i < 4; i++) { o[i] = sc[i][0]; arg[i] = sv[i][0] < minimal ? sj[i][0] : target; }
+        // ontology classes with the reference's shared, never-rewinding cursors (Test.h:113-135)
+        int lsup = a.sup_lef[target], rsup = a.sup_rig[target], lsub = a.sub_lef[target], rsub = a.sub_rig[target];
+        for (int i = 0; i < 4; i++) {
+            const int v = arg[i];
+            long long cls = 3;
+            if (v == target) cls = 0;
+            else {
+                while (lsup < rsup && a.sup_type[lsup] < v) lsup++;
+                if (lsup < rsup && a.sup_type[lsup] == v) cls = 1;
+                else {
+                    while (lsub < rsub && a.sub_type[lsub] < v) lsub++;
+                    if (lsub < rsub && a.sub_type[lsub] == v) cls = 2;
+                }
+            }
+            o[4 + i] = cls;
+        }
+    }
+}
+
+// candidates of getTailBatch / getHeadBatch (Test.h:11-26) for a batch of requests, on the device
+__global__ void candidates_kernel(const int4 *__restrict__ test, const int32_t *__restrict__ req_index,
+                                  const int32_t *__restrict__ req_head, int n_req, int E, int32_t *__restrict__ ch,
+                                  int32_t *__restrict__ ct, int32_t *__restrict__ cr) {
+    const long long total = (long long)n_req * E;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i / E), j = (int)(i - (long long)q * E);
+        const int4 tt = test[req_index[q]];
+        const bool head = req_head[q] != 0;
+        ch[i] = head ? j : tt.x;
+        ct[i] = head ? tt.y : j;
+        cr[i] = tt.z;
+    }
+}
+
+static int rank_requests(const float *d_scores, const std::vector<int32_t> &index, const std::vector<int32_t> &head,
+                         long long *h_out, hipStream_t stream, const int32_t *d_req_index, const int32_t *d_req_head) {
+    const int n = (int)index.size();
+    if (g_ed.out_cap < n) {
+        if (g_ed.out) (void)hipFree(g_ed.out);
+        g_ed.out = nullptr;
+        int rc = hip_check(hipMalloc(&g_ed.out, sizeof(long long) * 8 * (size_t)n), "alloc rank out");
+        if (rc) return rc;
+        g_ed.out_cap = n;
+    }
+    RankArgs a;
+    a.scores = d_scores; a.test = g_ed.test; a.all = g_ed.all; a.n_all = (long long)g_eh.all.size();
+    a.head_lef = g_ed.head_lef; a.head_rig = g_ed.head_rig; a.tail_lef = g_ed.tail_lef; a.tail_rig = g_ed.tail_rig;
+    a.head_type = g_ed.head_type; a.tail_type = g_ed.tail_type;
+    a.sup_lef = g_ed.sup_lef; a.sup_rig = g_ed.sup_rig; a.sub_lef = g_ed.sub_lef; a.sub_rig = g_ed.sub_rig;
+    a.sup_type = g_ed.sup_type; a.sub_type = g_ed.sub_type;
+    a.req_index = d_req_index; a.req_head = d_req_head; a.out = g_ed.out; a.E = (int)engine().index.ent_total;
+    hipLaunchKernelGGL(rank_kernel, dim3(n), dim3(256), 0, stream, a);
+    int rc = hip_check(hipMemcpyAsync(h_out, g_ed.out, sizeof(long long) * 8 * (size_t)n, hipMemcpyDeviceToHost, stream), "copy ranks");
+    if (rc) return rc;
+    return hip_check(hipStreamSynchronize(stream), "rank sync");
+}
+
+}  // namespace kge
+
+using namespace kge;
+
+extern "C" {
+
+void importTestFiles(void) {
+    Engine &e = engine();
+    g_eh = EvalHost();
+    g_ed.uploaded = false;
+    std::vector<int64_t> te, tr, va, tmp;
+    const std::string &d = e.in_path;
+    if (!read_all_longs(d + "relation2id.txt", tmp)) { set_error("`" + d + "relation2id.txt` does not exist"); return; }
+    if (!read_all_longs(d + "entity2id.txt", tmp)) { set_error("`" + d + "entity2id.txt` does not exist"); return; }
+    if (!read_all_longs(d + "test2id.txt", te)) { set_error("`" + d + "test2id.txt` does not exist"); return; }
+    if (!read_all_longs(d + "train2id.txt", tr)) { set_error("`" + d + "train2id.txt` does not exist"); return; }
+    if (!read_all_longs(d + "valid2id.txt", va)) { set_error("`" + d + "valid2id.txt` does not exist"); return; }
+    const int64_t T = te.empty() ? 0 : te[0], Tr = tr.empty() ? 0 : tr[0], V = va.empty() ? 0 : va[0];
+    if ((int64_t)te.size() < 1 + 3 * T || (int64_t)tr.size() < 1 + 3 * Tr || (int64_t)va.size() < 1 + 3 * V) { set_error("importTestFiles: truncated triple file"); return; }
+    g_eh.test_total = T; g_eh.valid_total = V; g_eh.triple_total = T + Tr + V;
+    auto push = [&](const std::vector<int64_t> &src, int64_t n, bool is_test) {
+        for (int64_t i = 0; i < n; i++) {  // on disk: head, tail, relation
+            const int32_t h = (int32_t)src[1 + 3 * i], t = (int32_t)src[2 + 3 * i], r = (int32_t)src[3 + 3 * i];
+            g_eh.all.push_back(Int4{h, r, t, 0});
+            if (is_test) g_eh.test.push_back(Int4{h, t, r, 0});
+        }
+    };
+    push(te, T, true); push(tr, Tr, false); push(va, V, false);
+    std::sort(g_eh.all.begin(), g_eh.all.end(), [](const Int4 &a, const Int4 &b) {        // Triple.h:18-20
+        if (a.x != b.x) return a.x < b.x; if (a.y != b.y) return a.y < b.y; return a.z < b.z; });
+    std::sort(g_eh.test.begin(), g_eh.test.end(), [](const Int4 &a, const Int4 &b) {      // Triple.h:30-32 (r,h,t)
+        if (a.z != b.z) return a.z < b.z; if (a.x != b.x) return a.x < b.x; return a.y < b.y; });
+    std::printf("The total of test triples is %ld.\n", (long)T);
+    std::printf("The total of valid triples is %ld.\n", (long)V);
+    g_eh.loaded = true;
+}
+
+void importTypeFiles(void) {
+    Engine &e = engine();
+    std::vector<int64_t> a;
+    if (!read_all_longs(e.in_path + "type_constrain.txt", a)) { set_error("`" + e.in_path + "type_constrain.txt` does not exist"); return; }
+    const int64_t R = e.index.rel_total;
+    g_eh.head_lef.assign(R, 0); g_eh.head_rig.assign(R, 0); g_eh.tail_lef.assign(R, 0); g_eh.tail_rig.assign(R, 0);
+    g_eh.head_type.clear(); g_eh.tail_type.clear();
+    size_t p = 1;
+    for (int64_t i = 0; i < R && p + 1 < a.size(); i++) {   // Reader.h:344-362
+        int64_t rel = a[p], tot = a[p + 1]; p += 2;
+        if (rel < 0 || rel >= R || p + tot > a.size()) { set_error("type_constrain.txt: malformed"); return; }
+        g_eh.head_lef[rel] = (int32_t)g_eh.head_type.size();
+        for (int64_t j = 0; j < tot; j++) g_eh.head_type.push_back((int32_t)a[p++]);
+        g_eh.head_rig[rel] = (int32_t)g_eh.head_type.size();
+        std::sort(g_eh.head_type.begin() + g_eh.head_lef[rel], g_eh.head_type.end());
+        if (p + 1 >= a.size()) break;
+        rel = a[p]; tot = a[p + 1]; p += 2;
+        if (rel < 0 || rel >= R || p + tot > a.size()) { set_error("type_constrain.txt: malformed"); return; }
+        g_eh.tail_lef[rel] = (int32_t)g_eh.tail_type.size();
+        for (int64_t j = 0; j < tot; j++) g_eh.tail_type.push_back((int32_t)a[p++]);
+        g_eh.tail_rig[rel] = (int32_t)g_eh.tail_type.size();
+        std::sort(g_eh.tail_type.begin() + g_eh.tail_lef[rel], g_eh.tail_type.end());
+    }
+    g_eh.types = true;
+    g_ed.uploaded = false;
+}
+
+void importOntologyFiles(void) {
+    Engine &e = engine();
+    std::printf("Reading %sontology_constrain.txt\n", e.in_path.c_str());
+    std::vector<int64_t> a;
+    if (!read_all_longs(e.in_path + "ontology_constrain.txt", a)) { set_error("`" + e.in_path + "ontology_constrain.txt` does not exist"); return; }
+    const int64_t E = e.index.ent_total;
+    g_eh.sup_lef.assign(E, 0); g_eh.sup_rig.assign(E, 0); g_eh.sub_lef.assign(E, 0); g_eh.sub_rig.assign(E, 0);
+    g_eh.sup_type.clear(); g_eh.sub_type.clear();
+    const int64_t n = a.empty() ? 0 : a[0];
+    size_t p = 1;
+    for (int64_t i = 0; i < n && p + 1 < a.size(); i++) {   // Reader.h:425-446
+        int64_t ent = a[p], tot = a[p + 1]; p += 2;
+        if (ent < 0 || ent >= E || p + tot > a.size()) { set_error("ontology_constrain.txt: malformed"); return; }
+        g_eh.sup_lef[ent] = (int32_t)g_eh.sup_type.size();
+        for (int64_t j = 0; j < tot; j++) g_eh.sup_type.push_back((int32_t)a[p++]);
+        g_eh.sup_rig[ent] = (int32_t)g_eh.sup_type.size();
+        std::sort(g_eh.sup_type.begin() + g_eh.sup_lef[ent], g_eh.sup_type.end());
+        if (p + 1 >= a.size()) break;
+        ent = a[p]; tot = a[p + 1]; p += 2;
+        if (ent < 0 || ent >= E || p + tot > a.size()) { set_error("ontology_constrain.txt: malformed"); return; }
+        g_eh.sub_lef[ent] = (int32_t)g_eh.sub_type.size();
+        for (int64_t j = 0; j < tot; j++) g_eh.sub_type.push_back((int32_t)a[p++]);
+        g_eh.sub_rig[ent] = (int32_t)g_eh.sub_type.size();
+        std::sort(g_eh.sub_type.begin() + g_eh.sub_lef[ent], g_eh.sub_type.end());
+    }
+    g_eh.onto = true;
+    g_ed.uploaded = false;
+}
+
+INT kge_eval_test_total(void) { return g_eh.test_total; }
+INT kge_eval_valid_total(void) { return g_eh.valid_total; }
+INT kge_eval_triple_total(void) { return g_eh.triple_total; }
+
+void getHeadBatch(INT index, INT *ph, INT *pt, INT *pr) {   // Test.h:11-17
+    if (!g_eh.loaded || index < 0 || index >= g_eh.test_total) { set_error("getHeadBatch: bad index / importTestFiles missing"); return; }
+    const Int4 &tt = g_eh.test[(size_t)index];
+    for (INT i = 0; i < engine().index.ent_total; i++) { ph[i] = i; pt[i] = tt.y; pr[i] = tt.z; }
+}
+
+void getTailBatch(INT index, INT *ph, INT *pt, INT *pr) {   // Test.h:20-26
+    if (!g_eh.loaded || index < 0 || index >= g_eh.test_total) { set_error("getTailBatch: bad index / importTestFiles missing"); return; }
+    const Int4 &tt = g_eh.test[(size_t)index];
+    for (INT i = 0; i < engine().index.ent_total; i++) { ph[i] = tt.x; pt[i] = i; pr[i] = tt.z; }
+}
+
+static INT *rank_one_host_scores(INT index, REAL *con, int head) {
+    // the reference returns `new INT[8]` that its callers never free (Test.h:37, Config.py:36-39);
+    // here a small ring of result slots is reused instead
+    static long long ring[64][8];
+    static int slot = 0;
+    long long *out = ring[slot];
+    slot = (slot + 1) % 64;
+    std::memset(out, 0, sizeof(long long) * 8);
+    if (ensure_eval_device()) return (INT *)out;
+    if (index < 0 || index >= g_eh.test_total) { set_error("testHead/testTail: index out of range"); return (INT *)out; }
+    const int64_t E = engine().index.ent_total;
+    if (g_ed.scores_cap < E) {
+        if (g_ed.scores) (void)hipFree(g_ed.scores);
+        g_ed.scores = nullptr;
+        if (hip_check(hipMalloc(&g_ed.scores, sizeof(float) * (size_t)E), "alloc scores")) return (INT *)out;
+        g_ed.scores_cap = E;
+    }
+    static int32_t *d_req = nullptr;
+    if (!d_req && hip_check(hipMalloc(&d_req, sizeof(int32_t) * 2), "alloc req")) return (INT *)out;
+    int32_t req[2] = {(int32_t)index, head};
+    if (hip_check(hipMemcpy(g_ed.scores, con, sizeof(float) * (size_t)E, hipMemcpyHostToDevice), "upload scores")) return (INT *)out;
+    if (hip_check(hipMemcpy(d_req, req, sizeof(req), hipMemcpyHostToDevice), "upload req")) return (INT *)out;
+    std::vector<int32_t> idx{(int32_t)index}, hd{head};
+    rank_requests(g_ed.scores, idx, hd, out, nullptr, d_req, d_req + 1);
+    return (INT *)out;
+}
+
+INT *testHead(INT index, REAL *con) { return rank_one_host_scores(index, con, 1); }   // Test.h:31-136
+INT *testTail(INT index, REAL *con) { return rank_one_host_scores(index, con, 0); }   // Test.h:141-249
+
+/* Triple-classification entry points of Base.so (Test.h:262-444).  SURVEY.md 8f next-row #2: NOT built
+ * yet.  They are exported so that the reference's Config.__init__ (Config.py:41-51), which declares
+ * argtypes for them unconditionally, binds to this library; calling one fails loudly. */
+static void not_built(const char *name) { set_error(std::string(name) + ": triple classification is not built in this engine yet (SURVEY.md 8f next-row #2)"); }
+void getTestBatch(INT *, INT *, INT *, INT *, INT *, INT *) { not_built("getTestBatch"); }
+void getValidBatch(INT *, INT *, INT *, INT *, INT *, INT *) { not_built("getValidBatch"); }
+void getBestThreshold(REAL *, REAL *, REAL *) { not_built("getBestThreshold"); }
+void test_triple_classification(REAL *, REAL *, REAL *, REAL *) { not_built("test_triple_classification"); }
+INT get_n_interval(INT, REAL *, REAL *) { not_built("get_n_interval"); return 0; }
+INT *get_TPFP(INT, REAL *, REAL *, REAL *, REAL *) { static INT z[2] = {0, 0}; not_built("get_TPFP"); return z; }
+
+/* Device-native evaluation of test triples [first, first+count): for each, the model's predict op over
+ * ALL entities as tail (and, if test_head != 0, as head) candidates, then the ranker.  out receives
+ * count x 2 x 8 int64: [i][0] = testTail result, [i][1] = testHead result (zeros when test_head == 0),
+ * each as the reference's 8-vector (distribute_training.py:465-590 consumes exactly these). */
+int kge_link_prediction(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES], INT first, INT count,
+                        INT test_head, int64_t *out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = ensure_eval_device();
+    if (rc) return rc;
+    if (!m || !tables || !out || first < 0 || count < 0 || first + count > g_eh.test_total) return fail(KGE_ERR_BAD_ARG, "kge_link_prediction: bad range");
+    const int64_t E = m->ent_total;
+    const int sides = test_head ? 2 : 1;
+    const int max_req = m->model == KGE_TRANSR ? 1 : 32;   // TransR's predict uses ONE matrix per call (TransR.py:83)
+    if (g_ed.scores_cap < (int64_t)max_req * E) {
+        if (g_ed.scores) (void)hipFree(g_ed.scores);
+        if (g_ed.cand) (void)hipFree(g_ed.cand);
+        g_ed.scores = nullptr; g_ed.cand = nullptr;
+        if ((rc = hip_check(hipMalloc(&g_ed.scores, sizeof(float) * (size_t)max_req * E), "alloc scores"))) return rc;
+        if ((rc = hip_check(hipMalloc(&g_ed.cand, sizeof(int32_t) * 3 * (size_t)max_req * E), "alloc candidates"))) return rc;
+        g_ed.scores_cap = (int64_t)max_req * E;
+    } else if (!g_ed.cand) {
+        if ((rc = hip_check(hipMalloc(&g_ed.cand, sizeof(int32_t) * 3 * (size_t)g_ed.scores_cap), "alloc candidates"))) return rc;
+    }
+    static int32_t *d_req = nullptr;
+    if (!d_req && (rc = hip_check(hipMalloc(&d_req, sizeof(int32_t) * 2 * 64), "alloc req"))) return rc;
+    std::memset(out, 0, sizeof(int64_t) * 16 * (size_t)count);
+    std::vector<int32_t> idx, hd;
+    std::vector<long long> res;
+    for (INT base = 0; base < count * sides; base += max_req) {
+        idx.clear(); hd.clear();
+        for (INT q = base; q < base + max_req && q < count * sides; q++) { idx.push_back((int32_t)(first + q / sides)); hd.push_back((int32_t)(q % sides)); }
+        const int n = (int)idx.size();
+        if ((rc = hip_check(hipMemcpyAsync(d_req, idx.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, stream), "upload req"))) return rc;
+        if ((rc = hip_check(hipMemcpyAsync(d_req + 64, hd.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, stream), "upload req"))) return rc;
+        int32_t *ch = g_ed.cand, *ct = g_ed.cand + (size_t)max_req * E, *cr = g_ed.cand + 2 * (size_t)max_req * E;
+        long long tot = (long long)n * E;
+        int blocks = (int)std::min<long long>((tot + 255) / 256, 4096);
+        hipLaunchKernelGGL(candidates_kernel, dim3(blocks), dim3(256), 0, stream, g_ed.test, d_req, d_req + 64, n, (int)E, ch, ct, cr);
+        if ((rc = launch_predict(*m, tables, ch, ct, cr, tot, g_ed.scores, stream))) return rc;
+        res.assign((size_t)n * 8, 0);
+        if ((rc = rank_requests(g_ed.scores, idx, hd, res.data(), stream, d_req, d_req + 64))) return rc;
+        for (int q = 0; q < n; q++) {
+            const INT i = idx[q] - first;
+            std::memcpy(out + (i * 2 + hd[q]) * 8, res.data() + (size_t)q * 8, sizeof(int64_t) * 8);
+        }
+    }
+    return KGE_OK;
+}
+
+}  // extern "C"

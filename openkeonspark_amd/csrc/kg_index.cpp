@@ -50,6 +50,16 @@ struct U3 { int32_t h, r, t; };
 
 }  // namespace
 
+bool read_all_longs(const std::string &path, std::vector<int64_t> &out) {
+    std::vector<char> buf;
+    out.clear();
+    if (!slurp(path, buf)) return false;
+    const char *p = buf.data();
+    int64_t v;
+    while (next_long(p, v)) out.push_back(v);
+    return true;
+}
+
 std::string load_openke_dir(const std::string &dir, int64_t &ent_total, int64_t &rel_total, int64_t &new_batch,
                             std::vector<int64_t> &h, std::vector<int64_t> &t, std::vector<int64_t> &r) {
     bool exists = false;

@@ -36,6 +36,9 @@ struct KgIndex {
 std::string load_openke_dir(const std::string &dir, int64_t &ent_total, int64_t &rel_total, int64_t &new_batch,
                             std::vector<int64_t> &h, std::vector<int64_t> &t, std::vector<int64_t> &r);
 
+// every whitespace-separated integer of a text file (fscanf("%ld") semantics); false if it cannot be opened
+bool read_all_longs(const std::string &path, std::vector<int64_t> &out);
+
 // Reader.h:102-177: dedup, the three sort orders, group ranges, tails-per-head / heads-per-tail.
 std::string build_index(KgIndex &ix, int64_t ent_total, int64_t rel_total, int64_t new_batch, int64_t n,
                         const int64_t *h, const int64_t *t, const int64_t *r);

@@ -1,0 +1,74 @@
+"""Link-prediction ranker on the device: the Base.so-compatible testHead/testTail (host score vectors)
+against the reference's golden outputs, and the device-native kge_link_prediction (scores never leave
+the GPU) against oracle predict + oracle ranker.  Integer results: bit-exact."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def make_config(kg, model="TransE", dim=32):
+    import openkeonspark_amd as pkg
+    con = pkg.Config()
+    con.set_in_path(os.path.join(GOLDEN, kg))
+    con.set_work_threads(1)
+    con.set_dimension(dim)
+    con.set_test_link_prediction(True)
+    con.init()
+    con.set_model_and_session(getattr(pkg, model))
+    return con
+
+
+@pytest.mark.parametrize("kg", ["kg_tiny", "kg_small"])
+def test_testhead_testtail_abi_matches_reference(kg):
+    z = np.load(os.path.join(GOLDEN, "lp_%s.npz" % kg))
+    con = make_config(kg)
+    L = con.lib
+    assert [L.getTestTotal(), L.getValidTotal(), L.getTripleTotal()] == z["totals"].tolist()
+    E = con.entTotal
+    for i in range(len(z["out"])):
+        # getTailBatch / getHeadBatch exactly as distribute_training.py:467,532 call them
+        h = np.zeros(E, np.int64); t = np.zeros(E, np.int64); r = np.zeros(E, np.int64)
+        L.getTailBatch(i, h.ctypes.data, t.ctypes.data, r.ctypes.data)
+        assert (h == z["triples"][i, 0]).all() and (t == np.arange(E)).all() and (r == z["triples"][i, 2]).all()
+        L.getHeadBatch(i, h.ctypes.data, t.ctypes.data, r.ctypes.data)
+        assert (h == np.arange(E)).all() and (t == z["triples"][i, 1]).all()
+        for side, fn in ((0, L.testHead), (1, L.testTail)):
+            sc = np.ascontiguousarray(z["scores"][i, side])
+            got = list(fn(i, sc.ctypes.data).contents)
+            assert got == z["out"][i, side].tolist(), (i, side)
+
+
+@pytest.mark.parametrize("model", ["TransE", "TransH", "TransD", "TransR"])
+def test_device_link_prediction_matches_oracle(model):
+    kg = "kg_small"
+    con = make_config(kg, model, dim=24)
+    ev = oracle.Eval(os.path.join(GOLDEN, kg))
+    params = con.get_parameters()
+    orc = oracle.Model(model.lower(), con.entTotal, con.relTotal, 24, 24, params=params)
+    n = 12
+    out, metrics = con.link_prediction(first=3, count=n, test_head=True)
+    E = con.entTotal
+    ar = np.arange(E)
+    mismatched = 0
+    for k in range(n):
+        i = 3 + k
+        h, t, r = ev.test_triple(i)
+        tail_scores = orc.predict(np.full(E, h), ar, np.full(E, r))
+        head_scores = orc.predict(ar, np.full(E, t), np.full(E, r))
+        want_t = ev.rank(i, tail_scores, head=False)
+        want_h = ev.rank(i, head_scores, head=True)
+        # scores are fp32 from two implementations: a candidate within an ulp of the target may flip a count
+        for got, want in ((out[k, 0], want_t), (out[k, 1], want_h)):
+            if got.tolist() != want.tolist():
+                mismatched += 1
+                assert np.abs(got[:4] - want[:4]).max() <= 1, (k, got, want)
+    assert mismatched <= 2
+    assert 0.0 <= metrics["r_filter_tot"] <= 1.0 and metrics["r_rank"] >= 1.0 and metrics["l_filter_rank"] >= 1.0
+    assert metrics["r_filter_rank"] <= metrics["r_rank"]
