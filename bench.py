@@ -105,8 +105,13 @@ def main():
             raise SystemExit("--gpus %d needs a torchrun launch with that many ranks" % args.gpus)
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # KGE_BENCH_FORCE_DIST=1 exercises the RCCL code path (process group, int32 all-reduce) with a single rank
+    use_dist = world > 1 or os.environ.get("KGE_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from openkeonspark_amd.synthetic import make_dataset, FB15K237
@@ -114,7 +119,7 @@ def main():
 
     if rank == 0:
         fb_dir = make_dataset("/tmp/okes_fb15k237_shaped", FB15K237)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     fb_dir = make_dataset("/tmp/okes_fb15k237_shaped", FB15K237)
 
@@ -140,8 +145,9 @@ def main():
     con.set_opt_method("Adam")
     con.init()
     con.set_model_and_session(TransE)
-    if world > 1:
+    if use_dist:
         con.init_distributed()
+        con.world_size = max(con.world_size, 2) if world == 1 else con.world_size  # force the all-reduce even with one rank
     sys.stdout.flush()
     con.lib.kge_clear_error()
     import ctypes
@@ -153,7 +159,7 @@ def main():
     n_local = con._n_local
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -165,7 +171,7 @@ def main():
         con.train_step(sync=False)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -218,7 +224,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(fb_dir)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -263,6 +263,9 @@ class Config(object):
         self._tab_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._tables])
         self._grad_ptrs = _lib.table_ptrs([g.data_ptr() for g in self._grads])
         self._dev_batch = None
+        self._side_stream = None
+        self._prefetched = None
+        self.prefetch_sampling = bool(getattr(self, "prefetch_sampling", False))  # measured: no gain at 1 GPU (the sampler competes with segsum/apply)
         self.global_step = 0
         # TransE: exact integer sign-count gradients instead of fp32 atomics (include/kge_mi355.h)
         n_neg = self.negative_ent + self.negative_rel
@@ -298,20 +301,50 @@ class Config(object):
     def _ensure_dev_batch(self, stride):
         import torch
         n = stride * (1 + self.negative_ent + self.negative_rel)
-        if self._dev_batch is None or self._dev_batch.shape[1] != n:
-            self._dev_batch = torch.zeros((3, n), dtype=torch.int32, device=self.device)
+        if self._dev_batch is None or self._dev_batch.shape[2] != n:
+            self._dev_batch = torch.zeros((2, 3, n), dtype=torch.int32, device=self.device)  # two slots: double buffer
         return self._dev_batch
 
-    def sample_device(self):
+    def sample_device(self, slot=0):
         """Sample this rank's slice of the next batch on the device; returns (int32[3,n] tensor, n_pos)."""
         stride = max(self._n_local, 1)
-        buf = self._ensure_dev_batch(stride)
+        buf = self._ensure_dev_batch(stride)[slot]
         nl = ctypes.c_int64(0)
         _lib.check(self.lib.kge_sampling_device(buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(),
                                                 self.batch_size, self.negative_ent, self.negative_rel,
                                                 self._thread_lo, self._thread_hi, stride, ctypes.byref(nl),
                                                 self._stream()), self.lib)
         return buf, nl.value
+
+    def _next_sampled_batch(self):
+        """The batch for this step, sampled one step ahead on a side stream: the sampler depends on the rng
+        streams and the dataset only, never on the parameters, so batch i+1 is drawn while step i's
+        reduction / gradient exchange / update run.  Same batches, same order, same bits."""
+        import torch
+        main = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+            self._slot = 0
+            self._prefetched = None
+        if self._prefetched is None:
+            dev, n_pos = self.sample_device(self._slot)
+        else:
+            dev, n_pos, ev = self._prefetched
+            main.wait_event(ev)
+        return dev, n_pos
+
+    def _prefetch_next_batch(self):
+        import torch
+        main = torch.cuda.current_stream()
+        done = torch.cuda.Event()
+        done.record(main)                      # the consumers of the OTHER slot (previous step) were enqueued before this
+        self._slot ^= 1
+        with torch.cuda.stream(self._side_stream):
+            self._side_stream.wait_event(done)  # slot reuse: its last reader is older than `done`
+            dev, n_pos = self.sample_device(self._slot)
+            ev = torch.cuda.Event()
+            ev.record(self._side_stream)
+        self._prefetched = (dev, n_pos, ev)
 
     def forward_backward(self, dev_batch, n_pos, stride, denom):
         """Add dLoss/dTables of the batch into the gradient accumulators; loss -> self._loss."""
@@ -349,7 +382,7 @@ class Config(object):
         import torch
         n_neg = self.negative_ent + self.negative_rel
         if batch_h is None:
-            dev, n_pos = self.sample_device()
+            dev, n_pos = self._next_sampled_batch() if self.prefetch_sampling else self.sample_device()
             stride = max(self._n_local, 1)
         else:
             if self.world_size != 1:
@@ -361,12 +394,16 @@ class Config(object):
         denom = self.batch_size * n_neg if batch_h is None else n_pos * n_neg
         if self.use_counts:
             self.forward_counts(dev, n_pos, stride, denom)
+            if batch_h is None and self.prefetch_sampling:
+                self._prefetch_next_batch()
             if self.world_size > 1:
                 from .parallel import allreduce_gradients
                 allreduce_gradients([self._counts, self._loss], self._pg)  # int32 SUM: exact
             self.apply_counts(denom)
         else:
             self.forward_backward(dev, n_pos, stride, denom)
+            if batch_h is None and self.prefetch_sampling:
+                self._prefetch_next_batch()
             if self.world_size > 1:
                 from .parallel import allreduce_gradients
                 allreduce_gradients(self._grads + [self._loss], self._pg)
@@ -488,7 +525,11 @@ class Config(object):
         return {n: g.detach().cpu().numpy() for n, g in zip(self.trainModel.table_names, self._grads)}
 
     def get_stream_states(self):
-        """rng stream states of the virtual sampler threads (next_random[], Random.h:6)."""
+        """rng stream states of the virtual sampler threads (next_random[], Random.h:6).  With sampling one
+        step ahead (prefetch_sampling) the states are those AFTER the prefetched batch was drawn."""
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         out = np.zeros(self.workThreads, dtype=np.uint64)
         _lib.check(self.lib.kge_get_stream_states(out.ctypes.data, self.workThreads), self.lib)
         return out

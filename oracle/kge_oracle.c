@@ -531,6 +531,11 @@ static float forward_all(const OrcModel *M, const i64 *bh, const i64 *bt, const 
     return total / (float)(B * N);
 }
 
+/* scores of the B positives and of the B*N negatives (ns[b*N+k]); lets a test see how close a hinge is to 0 */
+void orc_scores(const OrcModel *M, const i64 *bh, const i64 *bt, const i64 *br, i64 B, i64 N, float *ps, float *ns) {
+    forward_all(M, bh, bt, br, B, N, ps, ns, 1);
+}
+
 float orc_loss(const OrcModel *M, const i64 *bh, const i64 *bt, const i64 *br, i64 B, i64 N) {
     float *ps = malloc(sizeof(float) * (size_t)B), *ns = malloc(sizeof(float) * (size_t)(B * N));
     float l = forward_all(M, bh, bt, br, B, N, ps, ns, 1);

@@ -59,6 +59,7 @@ def lib():
         L.orc_sampling.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64]
         L.orc_loss.restype = f32
         L.orc_loss.argtypes = [vp, vp, vp, vp, i64, i64]
+        L.orc_scores.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp]
         L.orc_grad.restype = f32
         L.orc_grad.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp, ci]
         L.orc_sgd_step_sequential.restype = f32
@@ -253,6 +254,16 @@ class Model:
         bh, bt, br = self._batch(bh, bt, br)
         c = self._c()
         return float(lib().orc_loss(ctypes.byref(c), _p(bh), _p(bt), _p(br), B, N))
+
+    def hinge_margins(self, bh, bt, br, B, N):
+        """p_b - n_bk + margin for every (b,k): a value within rounding of 0 is a tie that two fp32
+        implementations may legitimately resolve differently (the hinge switches a whole gradient row)."""
+        bh, bt, br = self._batch(bh, bt, br)
+        c = self._c()
+        ps = np.zeros(B, np.float32)
+        ns = np.zeros(B * N, np.float32)
+        lib().orc_scores(ctypes.byref(c), _p(bh), _p(bt), _p(br), B, N, _p(ps), _p(ns))
+        return ps[:, None] - ns.reshape(B, N) + np.float32(self.margin)
 
     def grad(self, bh, bt, br, B, N, denom=None, nthreads=1):
         """-> (loss, {table: dense dL/dtable}).  denom defaults to B*N (reduce_mean)."""

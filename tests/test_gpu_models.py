@@ -17,6 +17,23 @@ def relerr(a, b):
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
 
 
+def seed_of(*key):
+    """Deterministic seed (Python's hash() of a tuple with strings changes from process to process)."""
+    import zlib
+    return zlib.crc32(repr(key).encode())
+
+
+def batch_without_ties(orc, make, B, N, tries=20):
+    """A batch none of whose hinges is within 1e-4 of zero.  max(x,0) switches a whole gradient row on
+    x >= 0; when x is within fp32 rounding of 0 the oracle and the kernels may disagree on the switch
+    (seen once in ~40 random batches), which is a property of the loss, not an error of either."""
+    for _ in range(tries):
+        bh, bt, br = make()
+        if np.abs(orc.hinge_margins(bh, bt, br, B, N)).min() > 1e-4:
+            return bh, bt, br
+    raise AssertionError("no tie-free batch found")
+
+
 def rand_batch(rng, E, R, B, n, nr, foreign=0.0, distinct=False):
     """distinct=True: a corrupted slot always differs from the positive's (as the reference's filtered
     sampler guarantees); otherwise a negative may coincide with its positive by chance."""
@@ -79,13 +96,13 @@ TRANSR_CASES = [(120, 9, 12, 8), (150, 7, 200, 200), (90, 5, 64, 100), (60, 4, 3
 def test_transr_forward_backward_matches_oracle(E, R, De, Dr, n, nr, foreign):
     """Relation-bucketed fp32-MFMA TransR (projection, dgrad, wgrad) against the oracle."""
     import torch
-    rng = np.random.default_rng(abs(hash((De, Dr, n, nr))) % 2**32)
+    rng = np.random.default_rng(seed_of(De, Dr, n, nr))
     B = 301
     params = oracle.init_params(oracle.TRANSR, E, R, De, Dr, seed=4)
     for k in params:
         params[k] = (params[k] * 3).astype(np.float32)
-    bh, bt, br = rand_batch(rng, E, R, B, n, nr, foreign)
     orc = oracle.Model("transr", E, R, De, Dr, margin=0.9, negative_rel=nr, params=params)
+    bh, bt, br = batch_without_ties(orc, lambda: rand_batch(rng, E, R, B, n, nr, foreign), B, n + nr)
     loss_o, g_o = orc.grad(bh, bt, br, B, n + nr)
     con = make_engine("transr", E, R, De, n, nr, margin=0.9, params=params, Dr=Dr)
     dev = torch.from_numpy(np.stack([bh, bt, br]).astype(np.int32)).cuda()
@@ -102,13 +119,13 @@ def test_transr_forward_backward_matches_oracle(E, R, De, Dr, n, nr, foreign):
 @pytest.mark.parametrize("n,nr,foreign", [(1, 0, 0.0), (5, 0, 0.0), (2, 1, 0.0), (3, 1, 0.3)])
 def test_forward_backward_matches_oracle(model, E, R, D, n, nr, foreign):
     import torch
-    rng = np.random.default_rng(abs(hash((model, D, n, nr))) % 2**32)
+    rng = np.random.default_rng(seed_of(model, D, n, nr))
     B = 257
     params = oracle.init_params(oracle.MODEL_IDS[model], E, R, D, D, seed=3)
     for k in params:
         params[k] = (params[k] * 3).astype(np.float32)
-    bh, bt, br = rand_batch(rng, E, R, B, n, nr, foreign)
     orc = oracle.Model(model, E, R, D, D, margin=0.9, negative_rel=nr, params=params)
+    bh, bt, br = batch_without_ties(orc, lambda: rand_batch(rng, E, R, B, n, nr, foreign), B, n + nr)
     loss_o, g_o = orc.grad(bh, bt, br, B, n + nr)
     con = make_engine(model, E, R, D, n, nr, margin=0.9, params=params)
     dev = torch.from_numpy(np.stack([bh, bt, br]).astype(np.int32)).cuda()
@@ -170,24 +187,36 @@ def test_transe_sign_count_gradient_matches_oracle(D, n, nr, foreign, reducer):
     backward): the gradient it applies, read back as p_before - p_after of an SGD step with lr = 1,
     against the oracle's dense gradient.  Few rows / many records per row: runs that span chunks,
     hub rows, and non sampler-shaped negatives (residual path)."""
-    rng = np.random.default_rng(abs(hash((D, n, nr))) % 2**32)
-    E, R, B = (97, 5, 700) if D != 100 else (1500, 9, 700)   # 1500 rows: several rows per LDS bucket
+    rng = np.random.default_rng(seed_of(D, n, nr))
+    E, R, B = (97, 5, 700) if D != 100 else (1500, 9, 700)   # 1500 rows: several rows per bucket
     params = oracle.init_params(oracle.TRANSE, E, R, D, D, seed=6)
     for k in params:
         params[k] = (params[k] * 3).astype(np.float32)
     orc = oracle.Model("transe", E, R, D, D, margin=0.8, negative_rel=nr, params=params)
     con = make_engine("transe", E, R, D, n, nr, margin=0.8, opt="SGD", alpha=1.0, params=params)
     assert con.use_counts
-    bh, bt, br = rand_batch(rng, E, R, B, n, nr, foreign)
+    bh, bt, br = batch_without_ties(orc, lambda: rand_batch(rng, E, R, B, n, nr, foreign), B, n + nr)
     loss_o, g_o = orc.grad(bh, bt, br, B, n + nr)
     loss_g = con.train_step(bh, bt, br, None)
     assert abs(loss_g - loss_o) <= RTOL * abs(loss_o)
     got = con.get_parameters()
+    unit = 1.0 / (B * (n + nr))
     for k in g_o:
         g_g = params[k].astype(np.float64) - got[k].astype(np.float64)
         # p - 1.0*g is rounded to fp32 at the parameter's magnitude: allow that quantum on top of 1e-5
         quantum = np.abs(params[k]).max() * 2.0 ** -23
-        assert np.abs(g_g - g_o[k]).max() <= RTOL * np.abs(g_o[k]).max() + quantum, k
+        diff = np.abs(g_g - g_o[k])
+        bad = diff > RTOL * np.abs(g_o[k]).max() + quantum
+        # d|e|/de jumps at e = 0: an element of h^+r^-t^ within fp32 rounding of zero (a few per million)
+        # gets sign +1 from one evaluation order and -1 from another (the kernel forms e with one fma, the
+        # oracle with add/sub).  One such element changes the integer count of ONE entry of a row by 2,
+        # i.e. that row's gradient by at most 2*unit/|row| (through the entry itself and, much less,
+        # through the normalise-backward's dot product).  A few rows may carry such a flip; every other
+        # row must agree to 1e-5.
+        min_norm = np.sqrt((params[k].astype(np.float64) ** 2).sum(1)).min()
+        bad_rows = np.nonzero(bad.any(1))[0]
+        assert len(bad_rows) <= 4, (k, len(bad_rows))
+        assert diff.max() <= 2.05 * unit / min_norm + RTOL * np.abs(g_o[k]).max() + quantum, (k, diff.max())
     assert not con._counts.any().item()
     for g in con.get_gradients().values():
         assert not g.any()
@@ -310,6 +339,7 @@ def test_sampled_training_matches_oracle_end_to_end(fb_dir):
     from openkeonspark_amd.TransE import TransE
     D, n = 100, 1
     con = Config()
+    con.prefetch_sampling = False   # so that the rng states after k steps are those after k batches
     con.set_in_path(fb_dir); con.set_work_threads(8); con.set_dimension(D); con.set_nbatches(400)
     con.set_ent_neg_rate(n); con.set_alpha(0.01); con.set_margin(1.0)
     con.init()
@@ -327,6 +357,28 @@ def test_sampled_training_matches_oracle_end_to_end(fb_dir):
     for k in orc.params:
         assert relerr(got[k], orc.params[k]) < 2e-5
     assert con.get_stream_states().tolist() == kg.stream_states().tolist()
+
+
+def test_prefetched_sampling_is_bit_identical(fb_dir):
+    """Drawing batch i+1 on a side stream while step i finishes changes nothing: same losses, same
+    parameters, bit for bit (the sampler never reads the parameters)."""
+    from openkeonspark_amd.Config import Config
+    from openkeonspark_amd.TransE import TransE
+    runs = []
+    for prefetch in (False, True):
+        con = Config()
+        con.prefetch_sampling = prefetch
+        con.set_in_path(fb_dir); con.set_work_threads(8); con.set_bern(1); con.set_dimension(64); con.set_nbatches(100)
+        con.set_ent_neg_rate(4); con.set_alpha(0.01); con.set_opt_method("Adam")
+        con.init()
+        seeds = np.array(oracle.libc_rand_sequence(8), dtype=np.uint64)
+        con.lib.kge_set_stream_states(seeds.ctypes.data, 8)
+        con.set_model_and_session(TransE)
+        losses = [con.train_step() for _ in range(6)]
+        runs.append((losses, con.get_parameters()))
+    assert runs[0][0] == runs[1][0]
+    for k in runs[0][1]:
+        assert np.array_equal(runs[0][1][k], runs[1][1][k])
 
 
 @pytest.mark.parametrize("model", ["transe", "transh", "transd", "transr"])

@@ -42,7 +42,8 @@ CASES = [("transe", 50, 7, 16, 16), ("transe", 40, 5, 100, 100), ("transh", 50, 
 def test_grad_matches_autograd(model, E, R, De, Dr, n, nr):
     if model == "transr" and nr > 0 and (n + nr) > 1:
         pytest.skip("reference graph itself is ill-shaped here (TransR.py:62 reshape), see torch_ref")
-    rng = np.random.default_rng(hash((model, De, n, nr)) % 2**32)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(repr((model, De, n, nr)).encode()))
     B = 37
     params = oracle.init_params(oracle.MODEL_IDS[model], E, R, De, Dr, seed=3)
     for k in params:  # larger values than xavier so that margins are active and inactive
