@@ -106,7 +106,9 @@ const char *kge_version(void);
 /* engine options (testing / measurement).
  *   "counts_force_sort": 1 = order the sign-count records with rocPRIM's radix sort instead of the
  *                        hand-written two-level counting sort (default 0)
- *   "time_emit":         1 = bracket the TransE emit kernel with HIP events on its launch stream */
+ *   "time_emit":         1 = bracket the TransE emit kernel with HIP events on its launch stream
+ *   "libc_rand_restart": restart the glibc-compatible seed generator, as in a fresh process (the next
+ *                        randReset then yields 1804289383, 846930886, ... again) */
 int kge_set_option(const char *name, INT value);
 /* elapsed time of the most recent launch of a timed kernel; name = "transe_emit" (needs time_emit) */
 int kge_last_kernel_ms(const char *name, float *ms);

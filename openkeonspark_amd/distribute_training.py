@@ -1,0 +1,255 @@
+"""Training / evaluation driver: the loop of /root/reference/distribute_training.py without Spark or TF.
+
+Same flags as `main_spark.py:299-324`, same `get_conf` (`distribute_training.py:32-71`), same per-step
+log line (`:283`), same checkpoint discovery (`get_last_step`, `:134-156`: the step is parsed from the
+`checkpoint` text file, `model.ckpt-<step>`), one checkpoint per epoch with `max_to_keep =
+patience + 5` (`:103,226-234`), loss-based early stop with `stop.txt` (`:336-360`), new-entity growth
+on restore (`main_spark.py:74-98`: xavier rows for parameters, zero rows for the Adam slots).  One
+process per GPU (torchrun) replaces the ps/worker cluster; rank 0 plays the chief.
+
+    python -m openkeonspark_amd.distribute_training --input_path DATA/ --output_path OUT/ --model TransE ...
+    torchrun --nproc-per-node 8 -m openkeonspark_amd.distribute_training ...
+
+Not built yet: the validation-ACCURACY early stop (`:295-333`, triple classification, SURVEY.md 8f
+next-row #2); only the loss criterion is evaluated.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+from .Config import Config
+from .Model import xavier_normal
+from .TransD import TransD
+from .TransE import TransE
+from .TransH import TransH
+from .TransR import TransR
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="OpenKEonSpark training loop on MI355X")
+    p.add_argument("--cluster_size", type=int, default=1, help="accepted for compatibility (ranks come from torchrun)")
+    p.add_argument("--num_ps", type=int, default=0, help="accepted for compatibility (no parameter servers)")
+    p.add_argument("--num_gpus", type=int, default=1)
+    p.add_argument("--cpp_lib_path", type=str, default=None)
+    p.add_argument("--input_path", type=str, default=None)
+    p.add_argument("--output_path", type=str, default=None)
+    p.add_argument("--train_times", type=int, default=100)
+    p.add_argument("--n_mini_batches", type=int, default=0)
+    p.add_argument("--alpha", type=float, default=0.00001)
+    p.add_argument("--margin", type=float, default=1.0)
+    p.add_argument("--bern_flag", type=int, default=0)
+    p.add_argument("--embedding_dimension", type=int, default=64)
+    p.add_argument("--ent_dimension", type=int, default=0)
+    p.add_argument("--rel_dimension", type=int, default=0)
+    p.add_argument("--ent_neg_rate", type=int, default=1)
+    p.add_argument("--rel_neg_rate", type=int, default=0)
+    p.add_argument("--optimizer", type=str, default="SGD")
+    p.add_argument("--early_stop_patience", type=int, default=5)
+    p.add_argument("--early_stop_stopping_step", type=int, default=1)
+    p.add_argument("--early_stop_start_step", type=int, default=1)
+    p.add_argument("--model", type=str, default="TransE")
+    p.add_argument("--debug", type=int, default=0)
+    p.add_argument("--mode", type=str, default="train")
+    p.add_argument("--test_head", type=int, default=0)
+    p.add_argument("--work_threads", type=int, default=8, help="virtual sampler threads (Config.py:65 hard-codes 8)")
+    p.add_argument("--seed", type=int, default=0, help="parameter initialisation seed")
+    return p.parse_args(argv)
+
+
+def get_conf(argv):
+    '''
+    Set the Config class using the program args (distribute_training.py:32-71)
+    '''
+    con = Config(cpp_lib_path=argv.cpp_lib_path)
+    con.set_in_path(argv.input_path)
+    con.set_export_files(argv.output_path)
+    if argv.mode != 'train':
+        con.set_test_link_prediction(True)
+    con.set_train_times(argv.train_times)
+    con.set_nbatches(argv.n_mini_batches)
+    con.set_alpha(argv.alpha)
+    con.set_margin(argv.margin)
+    con.set_bern(argv.bern_flag)
+    if argv.ent_dimension != 0 and argv.rel_dimension != 0:
+        con.set_ent_dimension(argv.ent_dimension)
+        con.set_rel_dimension(argv.rel_dimension)
+        con.hidden_size = argv.ent_dimension
+    else:
+        con.set_dimension(argv.embedding_dimension)
+    con.set_ent_neg_rate(argv.ent_neg_rate)
+    con.set_rel_neg_rate(argv.rel_neg_rate)
+    con.set_opt_method(argv.optimizer)
+    con.set_work_threads(getattr(argv, "work_threads", 8))
+    con.seed = getattr(argv, "seed", 0)
+    con.init()
+    name = argv.model.lower()
+    con.set_model({"transh": TransH, "transr": TransR, "transd": TransD}.get(name, TransE))
+    return con
+
+
+# ---------------------------------------------------------------------------------------------
+# checkpoints: TF Saver naming so that the reference's tooling finds the step
+# ---------------------------------------------------------------------------------------------
+def get_last_step(output_path):
+    '''
+    :return: last global step; 0 if there is no checkpoint (distribute_training.py:134-156)
+    '''
+    last_global_step = 0
+    try:
+        path = os.path.join(output_path, "checkpoint")
+        if os.path.isfile(path):
+            with open(path, "r") as f:
+                line = f.readline().replace('"', '').split(":")[1].split("/")
+                last_global_step = int(line[len(line) - 1].split("-")[1].strip())
+    except Exception as e:  # same tolerance as the reference
+        print("Error occured during last global step reading:")
+        print(e)
+    return last_global_step
+
+
+def checkpoint_arrays(con):
+    """Variables under the reference's names, Adam slots as `<var>/Adam`, `<var>/Adam_1`
+    (main_spark.py:74-98), plus the optimiser scalars and the sampler's rng streams."""
+    out = dict(con.get_parameters())
+    if con._adam:
+        for name, m, v in zip(con.trainModel.table_names, con._adam_m, con._adam_v):
+            out[name + "/Adam"] = m.detach().cpu().numpy()
+            out[name + "/Adam_1"] = v.detach().cpu().numpy()
+        out["beta1_power"] = np.float32(con._beta1_power)
+        out["beta2_power"] = np.float32(con._beta2_power)
+    out["global_step"] = np.int64(con.global_step)
+    out["rng_streams"] = con.get_stream_states()
+    return out
+
+
+def save_checkpoint(con, output_path, max_to_keep=10):
+    os.makedirs(output_path, exist_ok=True)
+    step = con.global_step
+    base = os.path.join(output_path, "model.ckpt-%d" % step)
+    np.savez(base + ".npz", **{k.replace("/", "__"): v for k, v in checkpoint_arrays(con).items()})
+    with open(os.path.join(output_path, "checkpoint"), "w") as f:
+        f.write('model_checkpoint_path: "%s"\n' % base)
+    kept = sorted(glob.glob(os.path.join(output_path, "model.ckpt-*.npz")),
+                  key=lambda p: int(p.rsplit("-", 1)[1][:-4]))
+    for old in kept[:-max_to_keep]:
+        os.remove(old)
+    return base + ".npz"
+
+
+def grow_table(table, rows, rng, zeros=False):
+    """Append rows for new entities (main_spark.py:74-98): xavier-initialised for a parameter table,
+    zeros for an Adam slot."""
+    table = np.asarray(table, dtype=np.float32)
+    extra = rows - table.shape[0]
+    if extra <= 0:
+        return table
+    new = np.zeros((extra, table.shape[1]), np.float32) if zeros else xavier_normal(rng, (extra, table.shape[1]))
+    return np.concatenate([table, new], axis=0)
+
+
+def restore_checkpoint(con, path, allow_growth=True):
+    """Load a checkpoint into an initialised Config (after set_model_and_session).  If the dataset
+    gained entities since the checkpoint was written, entity tables are grown as the reference's
+    `update_entities_and_model` does."""
+    import torch
+    z = {k.replace("__", "/"): v for k, v in np.load(path).items()}
+    rng = np.random.default_rng(getattr(con, "seed", 0) + 1)
+    shapes = con.trainModel.table_shapes()
+    for i, name in enumerate(con.trainModel.table_names):
+        rows = shapes[name][0]
+        tab = z[name]
+        if tab.shape[0] != rows:
+            if not allow_growth or tab.shape[0] > rows:
+                raise ValueError("checkpoint table %s has %d rows, model needs %d" % (name, tab.shape[0], rows))
+            tab = grow_table(tab, rows, rng)
+        con.set_parameters_by_name(name, tab)
+        if con._adam and name + "/Adam" in z:
+            con._adam_m[i].copy_(torch.from_numpy(grow_table(z[name + "/Adam"], rows, rng, zeros=True)))
+            con._adam_v[i].copy_(torch.from_numpy(grow_table(z[name + "/Adam_1"], rows, rng, zeros=True)))
+    if con._adam and "beta1_power" in z:
+        con._beta1_power = np.float32(z["beta1_power"])
+        con._beta2_power = np.float32(z["beta2_power"])
+    con.global_step = int(z.get("global_step", 0))
+    if "rng_streams" in z and len(z["rng_streams"]) == con.workThreads:
+        s = np.ascontiguousarray(z["rng_streams"], dtype=np.uint64)
+        con.lib.kge_set_stream_states(s.ctypes.data, con.workThreads)
+    return con.global_step
+
+
+# ---------------------------------------------------------------------------------------------
+def main_fun(argv):
+    """Train or evaluate (distribute_training.py:161-612)."""
+    import torch
+    distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    rank = int(os.environ.get("RANK", "0"))
+    if distributed:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    con = get_conf(argv)
+    con.device = "cuda:%d" % torch.cuda.current_device()
+    con.set_model_and_session(con.model)
+    if distributed:
+        con.init_distributed()
+    last_global_step = get_last_step(argv.output_path) if argv.output_path else 0
+    if last_global_step > 0:
+        restore_checkpoint(con, os.path.join(argv.output_path, "model.ckpt-%d.npz" % last_global_step))
+
+    if argv.mode != "train":
+        out, metrics = con.link_prediction(test_head=bool(argv.test_head))
+        if rank == 0:
+            print(json.dumps(metrics, indent=1))
+            if argv.output_path:
+                with open(os.path.join(argv.output_path, "lp_results.json"), "w") as f:
+                    json.dump(metrics, f, indent=1)
+        return metrics
+
+    iterations = con.train_times * con.nbatches + last_global_step      # distribute_training.py:205
+    patience = argv.early_stop_patience
+    stopping_step = argv.early_stop_stopping_step * con.nbatches
+    to_reach_step = argv.early_stop_start_step * con.nbatches + last_global_step
+    best_loss, wait_steps_loss, best_step = float("inf"), 0, last_global_step
+    t0 = time.time()
+    g = last_global_step
+    while g < iterations:
+        loss = con.train_step()
+        g = con.global_step
+        if rank == 0:
+            print('Global step: {} Epoch: {} Batch: {} loss: {}'.format(
+                g, int((g - last_global_step) / con.nbatches), int((g - last_global_step) % con.nbatches), loss))
+        if (g - last_global_step) % con.nbatches == 0 and rank == 0 and argv.output_path:
+            save_checkpoint(con, argv.output_path, max_to_keep=patience + 5)
+        if g < iterations and g >= to_reach_step:
+            while g >= to_reach_step:
+                to_reach_step += stopping_step
+            # loss criterion of distribute_training.py:336-360 (every rank sees the same all-reduced loss)
+            if loss < best_loss:
+                best_loss, wait_steps_loss, best_step = loss, 0, g
+            elif wait_steps_loss < patience:
+                wait_steps_loss += 1
+            if wait_steps_loss >= patience:
+                if rank == 0:
+                    print('Loss early stop. Losses has not been improved enough in {} times'.format(patience))
+                    if argv.output_path:
+                        with open(os.path.join(argv.output_path, "stop.txt"), "w") as f:
+                            f.write(str(best_step) + "\n")
+                break
+    if rank == 0 and argv.output_path:
+        save_checkpoint(con, argv.output_path, max_to_keep=patience + 5)
+        with open(os.path.join(argv.output_path, "time.txt"), "w") as f:   # main_spark.py:339-344
+            f.write(str(time.time() - t0))
+    if distributed:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return con
+
+
+if __name__ == "__main__":
+    main_fun(parse_args())
