@@ -74,8 +74,11 @@ void getTailBatch(INT index, INT *ph, INT *pt, INT *pr);  /* replaces base/Test.
  * reference leaks a `new INT[8]` per call). */
 INT *testHead(INT index, REAL *con);
 INT *testTail(INT index, REAL *con);
-/* Triple classification (base/Test.h:262-444): exported so that Config.py:41-51 binds, NOT built yet
- *  -- each call records an error retrievable with kge_last_error. */
+/* Triple classification (replace base/Test.h:252-444).  Host routines over
+ * validTotal / testTotal-long score arrays, as in the reference: negatives are the positives with a
+ * type-constrained new tail drawn with the (continuing) libc rand() sequence (Corrupt.h:118-137);
+ * thresholds by grid search with step 0.01f per relation; get_TPFP returns (n_interval+1)*2 INT in a
+ * library-owned buffer valid until the next call (the reference leaks a new[] per call). */
 void getTestBatch(INT *ph, INT *pt, INT *pr, INT *nh, INT *nt, INT *nr);
 void getValidBatch(INT *ph, INT *pt, INT *pr, INT *nh, INT *nt, INT *nr);
 void getBestThreshold(REAL *relThresh, REAL *score_pos, REAL *score_neg);

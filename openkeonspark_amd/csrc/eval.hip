@@ -11,6 +11,7 @@
 // over (score, j) -- the sequential loop's strict `<` keeps the first (smallest j) minimum -- and
 // their ontology classes are resolved by one thread with the reference's non-rewinding cursors.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 #include "engine.hpp"
@@ -40,6 +41,10 @@ struct EvalDev {
 
 static EvalHost g_eh;
 static EvalDev g_ed;
+// triple classification: valid triples (h,t,r) sorted by (r,h,t) (Reader.h:257) and the per-relation
+// ranges of the sorted valid / test lists (Reader.h:263-291)
+static std::vector<Int4> g_valid;
+static std::vector<int32_t> g_valid_lef, g_valid_rig, g_test_lef, g_test_rig;
 
 template <typename T, typename V>
 static int up(T *&dst, const std::vector<V> &src, const char *what) {
@@ -222,6 +227,7 @@ void importTestFiles(void) {
     Engine &e = engine();
     g_eh = EvalHost();
     g_ed.uploaded = false;
+    g_valid.clear();
     std::vector<int64_t> te, tr, va, tmp;
     const std::string &d = e.in_path;
     if (!read_all_longs(d + "relation2id.txt", tmp)) { set_error("`" + d + "relation2id.txt` does not exist"); return; }
@@ -351,16 +357,192 @@ static INT *rank_one_host_scores(INT index, REAL *con, int head) {
 INT *testHead(INT index, REAL *con) { return rank_one_host_scores(index, con, 1); }   // Test.h:31-136
 INT *testTail(INT index, REAL *con) { return rank_one_host_scores(index, con, 0); }   // Test.h:141-249
 
-/* Triple-classification entry points of Base.so (Test.h:262-444).  SURVEY.md 8f next-row #2: NOT built
- * yet.  They are exported so that the reference's Config.__init__ (Config.py:41-51), which declares
- * argtypes for them unconditionally, binds to this library; calling one fails loudly. */
-static void not_built(const char *name) { set_error(std::string(name) + ": triple classification is not built in this engine yet (SURVEY.md 8f next-row #2)"); }
-void getTestBatch(INT *, INT *, INT *, INT *, INT *, INT *) { not_built("getTestBatch"); }
-void getValidBatch(INT *, INT *, INT *, INT *, INT *, INT *) { not_built("getValidBatch"); }
-void getBestThreshold(REAL *, REAL *, REAL *) { not_built("getBestThreshold"); }
-void test_triple_classification(REAL *, REAL *, REAL *, REAL *) { not_built("test_triple_classification"); }
-INT get_n_interval(INT, REAL *, REAL *) { not_built("get_n_interval"); return 0; }
-INT *get_TPFP(INT, REAL *, REAL *, REAL *, REAL *) { static INT z[2] = {0, 0}; not_built("get_TPFP"); return z; }
+/* ------------------------------------------------------------------------------------------------
+ * Triple classification (Test.h:262-444).  These are the reference's HOST
+ * routines over validTotal / testTotal-long score arrays (run once per early-stop check, not a hot
+ * path): negatives drawn with libc rand() from the relation's tail type list until unknown
+ * (Corrupt.h:118-137), a per-relation threshold grid search with step `interval` = 0.01f
+ * (Setting.h:118), accuracy / TP-FP counts.  Restated in float exactly as written there.
+ * ---------------------------------------------------------------------------------------------- */
+static const float kInterval = 0.01f;   // Setting.h:118
+// min_score + i * interval (Test.h:326).  The reference is built with -O3 -march=native (make.sh:1), where
+// GCC contracts this expression into ONE fused multiply-add; a separate multiply and add rounds twice and
+// lands on different thresholds.  The fused form is what an FMA-capable host produces, so it is pinned here.
+static inline float grid_point(float mn, INT i) { return fmaf((float)i, kInterval, mn); }
+
+static bool find_host(int h, int t, int r) {   // Corrupt.h:104-115 on the host copy
+    const std::vector<Int4> &all = g_eh.all;
+    long long lef = 0, rig = (long long)all.size() - 1;
+    while (lef + 1 < rig) {
+        const long long mid = (lef + rig) >> 1;
+        const Int4 &m = all[(size_t)mid];
+        if (m.x < h || (m.x == h && m.y < r) || (m.x == h && m.y == r && m.z < t)) lef = mid; else rig = mid;
+    }
+    const Int4 &a = all[(size_t)lef], &b = all[(size_t)rig];
+    return (a.x == h && a.y == r && a.z == t) || (b.x == h && b.y == r && b.z == t);
+}
+
+// corrupt_head(0, h, r) on the host index (Corrupt.h:7-37), consuming rng stream 0; used only after 1000
+// failed type-constrained draws (Corrupt.h:131-133)
+static int corrupt_head_stream0(int h, int r) {
+    Engine &e = engine();
+    if (e.dev.streams_sync == 2 && e.dev.streams)
+        (void)hipMemcpy(e.streams.data(), e.dev.streams, sizeof(uint64_t) * e.streams.size(), hipMemcpyDeviceToHost);
+    if (e.streams.empty()) e.streams.assign(1, 0);
+    e.streams[0] = e.streams[0] * kLcgMul + kLcgAdd;
+    e.dev.streams_sync = 0;
+    // known tails of (h, r): any file-order triple of the group carries its [offset, length]
+    const KgIndex &ix = e.index;
+    int off = 0, len = 0;
+    for (size_t i = 0; i < ix.pos.size(); i++)
+        if (ix.pos[i].x == h && ix.pos[i].z == r) { off = ix.grp[i].x; len = ix.grp[i].y; break; }
+    const long long tmp = (long long)(e.streams[0] % (uint64_t)(ix.ent_total - len));
+    int lo = 0, hi = len;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)ix.tails_hr[(size_t)off + mid] - mid <= tmp) lo = mid + 1; else hi = mid; }
+    return (int)(tmp + lo);
+}
+
+static int corrupt_typed(int h, int r) {   // Corrupt.h:118-137
+    Engine &e = engine();
+    const int ll = g_eh.tail_lef.empty() ? 0 : g_eh.tail_lef[(size_t)r], rr = g_eh.tail_rig.empty() ? 0 : g_eh.tail_rig[(size_t)r];
+    if (rr <= ll) { set_error("getValidBatch/getTestBatch: relation without tail type list (importTypeFiles)"); return 0; }
+    for (int loop = 0;;) {
+        const int t = g_eh.tail_type[(size_t)(ll + e.libc.next() % (rr - ll))];   // Random.h:38-40 rand(a,b)
+        if (!find_host(h, t, r)) return t;
+        if (++loop >= 1000) return corrupt_head_stream0(h, r);
+    }
+}
+
+
+static void build_rel_ranges(const std::vector<Int4> &list, std::vector<int32_t> &lef, std::vector<int32_t> &rig) {
+    const int64_t R = engine().index.rel_total;
+    lef.assign((size_t)R, -1); rig.assign((size_t)R, -1);
+    for (size_t i = 0; i < list.size(); i++) {
+        const int r = list[i].z;
+        if (lef[(size_t)r] < 0) lef[(size_t)r] = (int32_t)i;
+        rig[(size_t)r] = (int32_t)i;
+    }
+}
+
+static bool ensure_classification_lists() {
+    if (!g_eh.loaded) { set_error("triple classification: importTestFiles has not been called"); return false; }
+    if (g_valid.size() != (size_t)g_eh.valid_total) {
+        // the valid triples are part of `all`; re-read them in file order is not needed: only the sorted list is used
+        std::vector<int64_t> va;
+        if (!read_all_longs(engine().in_path + "valid2id.txt", va)) { set_error("valid2id.txt does not exist"); return false; }
+        g_valid.clear();
+        for (int64_t i = 0; i < g_eh.valid_total; i++)
+            g_valid.push_back(Int4{(int32_t)va[1 + 3 * i], (int32_t)va[2 + 3 * i], (int32_t)va[3 + 3 * i], 0});
+        std::sort(g_valid.begin(), g_valid.end(), [](const Int4 &a, const Int4 &b) {
+            if (a.z != b.z) return a.z < b.z; if (a.x != b.x) return a.x < b.x; return a.y < b.y; });
+    }
+    build_rel_ranges(g_valid, g_valid_lef, g_valid_rig);
+    build_rel_ranges(g_eh.test, g_test_lef, g_test_rig);
+    return true;
+}
+
+static void fill_batch(const std::vector<Int4> &list, INT *ph, INT *pt, INT *pr, INT *nh, INT *nt, INT *nr) {
+    for (size_t i = 0; i < list.size(); i++) {   // Test.h:252-300: negative = positive with a new tail
+        ph[i] = list[i].x; pt[i] = list[i].y; pr[i] = list[i].z;
+        nh[i] = list[i].x; nr[i] = list[i].z;
+        nt[i] = corrupt_typed(list[i].x, list[i].z);
+    }
+}
+
+void getTestBatch(INT *ph, INT *pt, INT *pr, INT *nh, INT *nt, INT *nr) {
+    if (!ensure_classification_lists()) return;
+    fill_batch(g_eh.test, ph, pt, pr, nh, nt, nr);
+}
+
+void getValidBatch(INT *ph, INT *pt, INT *pr, INT *nh, INT *nt, INT *nr) {
+    if (!ensure_classification_lists()) return;
+    fill_batch(g_valid, ph, pt, pr, nh, nt, nr);
+}
+
+// min / max of the relation's validation scores and the grid size (Test.h:310-322, :394-410)
+static bool score_range(INT r, const REAL *sp, const REAL *sn, float &mn, float &mx, INT &n_interval) {
+    if (r < 0 || r >= (INT)g_valid_lef.size() || g_valid_lef[(size_t)r] == -1) return false;
+    const int lo = g_valid_lef[(size_t)r], hi = g_valid_rig[(size_t)r];
+    mn = sp[lo]; if (sn[lo] < mn) mn = sn[lo];
+    mx = sp[lo]; if (sn[lo] > mx) mx = sn[lo];
+    for (int i = lo + 1; i <= hi; i++) {
+        if (sp[i] < mn) mn = sp[i];
+        if (sp[i] > mx) mx = sp[i];
+        if (sn[i] < mn) mn = sn[i];
+        if (sn[i] > mx) mx = sn[i];
+    }
+    n_interval = (INT)((mx - mn) / kInterval);
+    return true;
+}
+
+void getBestThreshold(REAL *relThresh, REAL *score_pos, REAL *score_neg) {   // Test.h:304-341
+    if (!ensure_classification_lists()) return;
+    for (INT r = 0; r < engine().index.rel_total; r++) {
+        float mn, mx; INT n_interval;
+        if (!score_range(r, score_pos, score_neg, mn, mx, n_interval)) continue;
+        const int lo = g_valid_lef[(size_t)r], hi = g_valid_rig[(size_t)r];
+        const INT total = (INT)(hi - lo + 1) * 2;
+        float bestThresh = 0.f, bestAcc = 0.f;
+        for (INT i = 0; i <= n_interval; i++) {
+            const float tmpThresh = grid_point(mn, i);
+            INT correct = 0;
+            for (int j = lo; j <= hi; j++) {
+                if (score_pos[j] <= tmpThresh) correct++;
+                if (score_neg[j] > tmpThresh) correct++;
+            }
+            const float tmpAcc = (float)(1.0 * correct / total);
+            if (i == 0 || tmpAcc > bestAcc) { bestAcc = tmpAcc; bestThresh = tmpThresh; }
+        }
+        relThresh[r] = bestThresh;
+    }
+}
+
+void test_triple_classification(REAL *relThresh, REAL *score_pos, REAL *score_neg, REAL *acc_addr) {   // Test.h:347-387
+    if (!ensure_classification_lists()) return;
+    INT TP = 0, TN = 0, FP = 0, FN = 0;
+    for (INT r = 0; r < engine().index.rel_total; r++) {
+        if (g_valid_lef[(size_t)r] == -1 || g_test_lef[(size_t)r] == -1) continue;
+        for (int i = g_test_lef[(size_t)r]; i <= g_test_rig[(size_t)r]; i++) {
+            if (score_pos[i] <= relThresh[r]) TP++; else FN++;
+            if (score_neg[i] > relThresh[r]) TN++; else FP++;
+        }
+    }
+    const double accuracy = 1.0 * (TP + TN) / (TP + TN + FP + FN);
+    const double precision = 1.0 * TP / (TP + FP);
+    const double recall = 1.0 * TP / (TP + FN);
+    const double fmeasure = (2 * precision * recall) / (precision + recall);
+    std::printf("triple classification accuracy is %lf\n", accuracy);
+    std::printf("triple classification precision is %lf\n", precision);
+    std::printf("triple classification recall is %lf\n", recall);
+    std::printf("triple classification f-measure is %lf\n", fmeasure);
+    if (acc_addr) acc_addr[0] = (float)(1.0 * (TP + TN) / (TP + TN + FP + FN));
+}
+
+INT get_n_interval(INT r, REAL *score_pos, REAL *score_neg) {   // Test.h:390-407
+    if (!ensure_classification_lists()) return 0;
+    float mn, mx; INT n;
+    return score_range(r, score_pos, score_neg, mn, mx, n) ? n : 0;
+}
+
+INT *get_TPFP(INT r, REAL *score_pos, REAL *score_neg, REAL *score_pos_test, REAL *score_neg_test) {   // Test.h:410-444
+    static std::vector<INT> buf;   // the reference leaks a new INT[] per call
+    if (!ensure_classification_lists()) return nullptr;
+    float mn, mx; INT n_interval;
+    if (!score_range(r, score_pos, score_neg, mn, mx, n_interval)) return nullptr;
+    buf.assign((size_t)(n_interval + 1) * 2, 0);
+    for (INT i = 0; i <= n_interval; i++) {
+        const float tmpThresh = grid_point(mn, i);
+        INT TP = 0, FP = 0;
+        if (g_test_lef[(size_t)r] != -1)
+            for (int j = g_test_lef[(size_t)r]; j <= g_test_rig[(size_t)r]; j++) {
+                if (score_pos_test[j] <= tmpThresh) TP++;
+                if (score_neg_test[j] <= tmpThresh) FP++;
+            }
+        buf[(size_t)i] = TP;
+        buf[(size_t)(i + n_interval + 1)] = FP;
+    }
+    return buf.data();
+}
 
 /* Device-native evaluation of test triples [first, first+count): for each, the model's predict op over
  * ALL entities as tail (and, if test_head != 0, as head) candidates, then the ranker.  out receives

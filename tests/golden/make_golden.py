@@ -112,6 +112,42 @@ def lp_worker(kg_dir, out_path, n_triples, seed):
                         triples=triples, scores=scores, out=out)
 
 
+def tc_worker(kg_dir, out_path, seed):
+    """Reference triple classification (Test.h:252-444) in a fresh process: type-constrained negatives
+    drawn with libc rand(), thresholds, accuracy, ROC counts, on seeded score arrays."""
+    import ctypes
+    from oracle.oracle import ReferenceSampler, _p
+    ref = ReferenceSampler(kg_dir, work_threads=1, bern=0)     # randReset consumed ONE libc draw
+    ref.init_link_prediction()
+    L = ref.L
+    vp = ctypes.c_void_p
+    L.getValidBatch.argtypes = [vp] * 6; L.getTestBatch.argtypes = [vp] * 6
+    L.getBestThreshold.argtypes = [vp] * 3
+    L.test_triple_classification.argtypes = [vp] * 4
+    L.get_n_interval.argtypes = [ctypes.c_int64, vp, vp]; L.get_n_interval.restype = ctypes.c_int64
+    L.get_TPFP.argtypes = [ctypes.c_int64, vp, vp, vp, vp]; L.get_TPFP.restype = ctypes.POINTER(ctypes.c_int64)
+    V, T, R = ref.validTotal, ref.testTotal, ref.relTotal
+    valid = [np.zeros(V, np.int64) for _ in range(6)]
+    test = [np.zeros(T, np.int64) for _ in range(6)]
+    L.getValidBatch(*[_p(a) for a in valid])
+    L.getTestBatch(*[_p(a) for a in test])
+    rng = np.random.default_rng(seed)
+    vpos = np.round(rng.normal(2.0, 0.7, V), 3).astype(np.float32); vneg = np.round(rng.normal(3.0, 0.7, V), 3).astype(np.float32)
+    tpos = np.round(rng.normal(2.0, 0.7, T), 3).astype(np.float32); tneg = np.round(rng.normal(3.0, 0.7, T), 3).astype(np.float32)
+    thresh = np.full(R, -1.0, np.float32)
+    L.getBestThreshold(_p(thresh), _p(vpos), _p(vneg))
+    acc = np.zeros(1, np.float32)
+    L.test_triple_classification(_p(thresh), _p(tpos), _p(tneg), _p(acc))
+    n_int = np.array([L.get_n_interval(r, _p(vpos), _p(vneg)) for r in range(R)], np.int64)
+    tpfp = {}
+    for r in range(R):
+        ptr = L.get_TPFP(r, _p(vpos), _p(vneg), _p(tpos), _p(tneg))
+        if ptr:
+            tpfp["tpfp_%d" % r] = np.array([ptr[i] for i in range(int(n_int[r] + 1) * 2)], np.int64)
+    np.savez_compressed(out_path, valid=np.stack(valid), test=np.stack(test), vpos=vpos, vneg=vneg, tpos=tpos, tneg=tneg,
+                        thresh=thresh, acc=acc, n_interval=n_int, **tpfp)
+
+
 def worker(kg_dir, W, bern, out_path, shapes, calls):
     from oracle.oracle import ReferenceSampler
     ref = ReferenceSampler(kg_dir, work_threads=W, bern=bern)
@@ -157,6 +193,10 @@ def main():
         a = json.loads(sys.argv[2])
         lp_worker(a["kg"], a["out"], a["n"], a["seed"])
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--tc":
+        a = json.loads(sys.argv[2])
+        tc_worker(a["kg"], a["out"], a["seed"])
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--digest":
         a = json.loads(sys.argv[2])
         digest_worker(a["kg"], a["W"], a["bern"], a["B"], a["n"], a["nr"], a["calls"], a["out"])
@@ -177,6 +217,10 @@ def main():
         out = os.path.join(HERE, "lp_%s.npz" % kg)
         arg = dict(kg=os.path.join(HERE, kg) + "/", out=out, n=30, seed=5)
         subprocess.check_call([sys.executable, __file__, "--lp", json.dumps(arg)], stdout=subprocess.DEVNULL)
+        print("wrote", os.path.relpath(out, ROOT))
+        out = os.path.join(HERE, "tc_%s.npz" % kg)
+        arg = dict(kg=os.path.join(HERE, kg) + "/", out=out, seed=9)
+        subprocess.check_call([sys.executable, __file__, "--tc", json.dumps(arg)], stdout=subprocess.DEVNULL)
         print("wrote", os.path.relpath(out, ROOT))
     # FB15k-237-shaped synthetic graph: generated (not committed), digests committed
     from openkeonspark_amd.synthetic import make_dataset, FB15K237
