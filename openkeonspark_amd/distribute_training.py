@@ -10,8 +10,13 @@ process per GPU (torchrun) replaces the ps/worker cluster; rank 0 plays the chie
     python -m openkeonspark_amd.distribute_training --input_path DATA/ --output_path OUT/ --model TransE ...
     torchrun --nproc-per-node 8 -m openkeonspark_amd.distribute_training ...
 
-Not built yet: the validation-ACCURACY early stop (`:295-333`, triple classification, SURVEY.md 8f
-next-row #2); only the loss criterion is evaluated.
+Early stop: both criteria of the reference -- validation accuracy of triple classification
+(`:295-333`: thresholds from `getBestThreshold` on the validation positives / type-constrained
+negatives of `getValidBatch`) when valid2id.txt / test2id.txt / type_constrain.txt are present, and the
+loss (`:336-360`).  One deliberate difference: the reference then calls
+`test_triple_classification(relThresh, valid_scores...)`, which walks the TEST set's per-relation
+ranges over the validation score arrays (`Test.h:352-353` with `distribute_training.py:312`); here the
+accuracy is computed over the validation triples the thresholds were fitted on.
 """
 import argparse
 import glob
@@ -182,6 +187,38 @@ def restore_checkpoint(con, path, allow_growth=True):
 
 
 # ---------------------------------------------------------------------------------------------
+def _init_validation(con, argv):
+    """getValidBatch once before the loop (distribute_training.py:262): validation positives and their
+    type-constrained negatives, or None when the evaluation files are absent."""
+    path = con.in_path if con.in_path.endswith("/") else con.in_path + "/"
+    if not all(os.path.exists(path + f) for f in ("valid2id.txt", "test2id.txt", "type_constrain.txt")):
+        return None
+    import ctypes
+    from . import _lib
+    L = con.lib
+    L.kge_clear_error()
+    L.importTestFiles()
+    L.importTypeFiles()
+    _lib.raise_if_error(L)
+    n = L.getValidTotal()
+    arrs = [np.zeros(n, np.int64) for _ in range(6)]
+    L.getValidBatch.argtypes = [ctypes.c_void_p] * 6
+    L.getBestThreshold.argtypes = [ctypes.c_void_p] * 3
+    L.getValidBatch(*[a.ctypes.data for a in arrs])
+    _lib.raise_if_error(L)
+    return arrs
+
+
+def _validation_accuracy(con, valid):
+    ph, pt, pr, nh, nt, nr = valid
+    pos = np.ascontiguousarray(con.test_step(ph, pt, pr).reshape(-1), dtype=np.float32)
+    neg = np.ascontiguousarray(con.test_step(nh, nt, nr).reshape(-1), dtype=np.float32)
+    thresh = np.zeros(con.relTotal, np.float32)
+    con.lib.getBestThreshold(thresh.ctypes.data, pos.ctypes.data, neg.ctypes.data)
+    correct = (pos <= thresh[pr]).sum() + (neg > thresh[nr]).sum()
+    return float(correct) / (2.0 * max(len(pos), 1))
+
+
 def main_fun(argv):
     """Train or evaluate (distribute_training.py:161-612)."""
     import torch
@@ -210,6 +247,8 @@ def main_fun(argv):
                     json.dump(metrics, f, indent=1)
         return metrics
 
+    valid = _init_validation(con, argv)
+    best_acc, wait_steps_acc, best_step_acc = -1.0, 0, last_global_step
     iterations = con.train_times * con.nbatches + last_global_step      # distribute_training.py:205
     patience = argv.early_stop_patience
     stopping_step = argv.early_stop_stopping_step * con.nbatches
@@ -228,6 +267,21 @@ def main_fun(argv):
         if g < iterations and g >= to_reach_step:
             while g >= to_reach_step:
                 to_reach_step += stopping_step
+            if valid is not None:   # accuracy criterion of distribute_training.py:295-333
+                acc = _validation_accuracy(con, valid)
+                if argv.debug and rank == 0:
+                    print("[ Early Stop Check (Accuracy) ] best %.10f now %.10f" % (best_acc, acc))
+                if acc > best_acc:
+                    best_acc, wait_steps_acc, best_step_acc = acc, 0, g
+                elif wait_steps_acc < patience:
+                    wait_steps_acc += 1
+                if wait_steps_acc >= patience:
+                    if rank == 0:
+                        print('Accuracy early stop. Accuracy has not been improved enough in {} times'.format(patience))
+                        if argv.output_path:
+                            with open(os.path.join(argv.output_path, "stop.txt"), "w") as f:
+                                f.write(str(best_step_acc) + "\n")
+                    break
             # loss criterion of distribute_training.py:336-360 (every rank sees the same all-reduced loss)
             if loss < best_loss:
                 best_loss, wait_steps_loss, best_step = loss, 0, g

@@ -90,3 +90,15 @@ def test_loss_early_stop_writes_stop_file(tmp_path):
                           "--n_mini_batches", "2", "--alpha", "0.0", "--train_times", "50", "--early_stop_patience", "2"])
     con = dt.main_fun(args)                               # lr = 0: the loss never improves after the first check
     assert os.path.exists(os.path.join(out, "stop.txt")) and con.global_step < 50 * con.nbatches
+
+
+@pytest.mark.gpu
+def test_accuracy_early_stop_uses_triple_classification(tmp_path, capsys):
+    out = str(tmp_path / "acc")
+    args = dt.parse_args(["--input_path", os.path.join(GOLDEN, "kg_small"), "--output_path", out, "--embedding_dimension", "16",
+                          "--n_mini_batches", "2", "--alpha", "0.0", "--train_times", "40", "--early_stop_patience", "2",
+                          "--debug", "1"])
+    con = dt.main_fun(args)   # lr = 0: neither accuracy nor loss can improve -> stops after `patience` checks
+    text = capsys.readouterr().out
+    assert "Early Stop Check (Accuracy)" in text and "early stop" in text
+    assert os.path.exists(os.path.join(out, "stop.txt")) and con.global_step < 40 * con.nbatches
