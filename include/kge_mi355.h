@@ -109,6 +109,9 @@ const char *kge_version(void);
 /* engine options (testing / measurement).
  *   "counts_force_sort": 1 = order the sign-count records with rocPRIM's radix sort instead of the
  *                        hand-written two-level counting sort (default 0)
+ *   "inv_table_max_bytes": the TransE emit kernel reads 1/|row| from a per-row table rebuilt every step while
+ *                        the two tables are at most this many bytes (default 256 MiB); larger tables (or 0)
+ *                        compute the norms from the gathered rows
  *   "time_emit":         1 = bracket the TransE emit kernel with HIP events on its launch stream
  *   "libc_rand_restart": restart the glibc-compatible seed generator, as in a fresh process (the next
  *                        randReset then yields 1804289383, 846930886, ... again) */
@@ -208,6 +211,30 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
                               int32_t *d_counts, float *d_resid_ent, float *d_resid_rel, float *d_loss, void *stream);
 int kge_transe_apply_counts(float *d_p, float *d_m, float *d_v, int32_t *d_counts, float *d_resid, int64_t rows, int32_t dim,
                             INT denom, int32_t adam, float lr, float beta1, float beta2, float eps, void *stream);
+
+/* ---- TransE sign-count path, stage level: for tables too large for a dense count image and for the
+ * multi-GPU exchange, where the int8 records (8x smaller than fp32 gradient rows) are the wire format ----
+ *   kge_transe_record_dwords : dwords per record for this embedding width
+ *   kge_transe_emit_records  : stage 1 into CALLER buffers d_rec [n_pos*(3+n_neg), dwords], d_dst [n_pos*(3+n_neg)]
+ *                              (destination row in the [0,E)+[E,E+R) row space, -1 = no record)
+ *   kge_transe_reduce_records: order any number of records (e.g. all ranks' records after an all-gather) by
+ *                              destination and sum them into a COMPACT image: d_rows[i] = touched row,
+ *                              d_row_counts[i, D] = its int32 count vector, *d_n_rows = how many (device scalar);
+ *                              buffers sized for n_records rows; d_dst is overwritten
+ *   kge_transe_apply_rows_sgd: SGD on the touched rows only (same arithmetic as kge_transe_apply_counts)
+ *   kge_transe_deferred_groups: groups of the last emit whose negatives were not sampler-shaped (each negative
+ *                              differing from its positive in exactly one slot).  With residual accumulators they
+ *                              were handled by the fp32 path; with d_resid_* == NULL they were SKIPPED and the
+ *                              caller must treat a non-zero count as an error.  Synchronises. */
+INT kge_transe_record_dwords(const kge_model_desc *m);
+int kge_transe_deferred_groups(int32_t *n_groups);
+int kge_transe_emit_records(const kge_model_desc *m, const float *d_ent, const float *d_rel, const int32_t *d_h, const int32_t *d_t,
+                            const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom, uint32_t *d_rec, int32_t *d_dst,
+                            float *d_resid_ent, float *d_resid_rel, float *d_loss, void *stream);
+int kge_transe_reduce_records(const kge_model_desc *m, const uint32_t *d_rec, int32_t *d_dst, INT n_records, int32_t *d_rows,
+                              int32_t *d_row_counts, int32_t *d_n_rows, void *stream);
+int kge_transe_apply_rows_sgd(const kge_model_desc *m, float *d_ent, float *d_rel, const int32_t *d_rows, const int32_t *d_row_counts,
+                              const int32_t *d_n_rows, INT max_rows, INT denom, float lr, void *stream);
 
 /* Device-native link prediction for test triples [first, first+count) (replaces the loop
  * distribute_training.py:465-590: getTailBatch -> sess.run(predict) -> testTail, and the head side when

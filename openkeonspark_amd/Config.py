@@ -252,8 +252,23 @@ class Config(object):
         m = self.trainModel
         self._desc = m.descriptor()
         self._tables = [m.parameter_lists[n] for n in m.table_names]
-        self._grads = [torch.zeros_like(t) for t in self._tables]
         self._adam = self.opt_method in ("Adam", "adam")  # distribute_training.py:95
+        # TransE: exact integer sign-count gradients instead of fp32 atomics (include/kge_mi355.h)
+        n_neg = self.negative_ent + self.negative_rel
+        self.use_counts = bool(getattr(self, "use_counts", True)) and bool(
+            self.lib.kge_transe_counts_supported(ctypes.byref(self._desc), n_neg))
+        # sparse-row mode: no dense gradient / count image at all.  The int8 records are reduced into a compact
+        # [touched rows, D] image and only those rows are updated; across ranks the records themselves are
+        # all-gathered (the sparse touched-row exchange of BASELINE config #5).  SGD only: TF1's sparse Adam
+        # sweeps every row of m, v and the table each step, which is the dense path by definition.
+        table_bytes = (self.entTotal + self.relTotal) * self.hidden_size * 4
+        sparse = getattr(self, "sparse_rows", None)
+        if sparse is None:
+            sparse = table_bytes > int(getattr(self, "sparse_threshold_bytes", 8 << 30))
+        self.sparse_rows = bool(sparse) and self.use_counts and not self._adam
+        if sparse and not self.sparse_rows and getattr(self, "sparse_rows", None):
+            raise KgeError("sparse_rows needs TransE (sign-count path) with SGD")
+        self._grads = [] if self.sparse_rows else [torch.zeros_like(t) for t in self._tables]
         if self._adam:
             self._adam_m = [torch.zeros_like(t) for t in self._tables]
             self._adam_v = [torch.zeros_like(t) for t in self._tables]
@@ -267,11 +282,8 @@ class Config(object):
         self._prefetched = None
         self.prefetch_sampling = bool(getattr(self, "prefetch_sampling", False))  # measured: no gain at 1 GPU (the sampler competes with segsum/apply)
         self.global_step = 0
-        # TransE: exact integer sign-count gradients instead of fp32 atomics (include/kge_mi355.h)
-        n_neg = self.negative_ent + self.negative_rel
-        self.use_counts = bool(getattr(self, "use_counts", True)) and bool(
-            self.lib.kge_transe_counts_supported(ctypes.byref(self._desc), n_neg))
-        if self.use_counts:
+        self._sparse_buf = None
+        if self.use_counts and not self.sparse_rows:
             self._counts = torch.zeros((self.entTotal + self.relTotal, self.hidden_size), dtype=torch.int32,
                                        device=self.device)
         self._setup_partition()
@@ -392,7 +404,11 @@ class Config(object):
             n_pos = host.shape[1] // (1 + n_neg)
             stride = n_pos
         denom = self.batch_size * n_neg if batch_h is None else n_pos * n_neg
-        if self.use_counts:
+        if self.sparse_rows:
+            self._sparse_step(dev, n_pos, stride, denom, check_shape=batch_h is not None)
+            if batch_h is None and self.prefetch_sampling:
+                self._prefetch_next_batch()
+        elif self.use_counts:
             self.forward_counts(dev, n_pos, stride, denom)
             if batch_h is None and self.prefetch_sampling:
                 self._prefetch_next_batch()
@@ -410,6 +426,67 @@ class Config(object):
             self.apply_gradients()
         self.trainModel.loss = self._loss
         return float(self._loss.item()) if sync else self._loss
+
+    def _sparse_step(self, dev_batch, n_pos, stride, denom, check_shape=False):
+        """Sparse-row TransE step: emit int8 records -> (all-gather over ranks) -> compact per-row counts ->
+        SGD on the touched rows.  Bitwise the same update as the dense count image (integer sums)."""
+        import torch
+        from .parallel import allgather_records, allreduce_gradients, max_slice_positions
+        n_neg = self.negative_ent + self.negative_rel
+        D = self.hidden_size
+        W = self.world_size
+        if W > 1:  # every rank contributes the same number of record slots (padding has destination -1)
+            stride = max(stride, max_slice_positions(self.lib, self.batch_size, W, self.workThreads))
+        m_local = stride * (3 + n_neg)
+        dw = int(self.lib.kge_transe_record_dwords(ctypes.byref(self._desc)))
+        buf = self._sparse_buf
+        if buf is None or buf["m_local"] != m_local or buf["W"] != W:
+            dev = self.device
+            buf = dict(m_local=m_local, W=W,
+                       rec=torch.empty((m_local, dw), dtype=torch.int32, device=dev),
+                       dst=torch.empty(m_local, dtype=torch.int32, device=dev),
+                       rows=torch.empty(m_local * W, dtype=torch.int32, device=dev),
+                       row_counts=torch.empty((m_local * W, D), dtype=torch.int32, device=dev),
+                       n_rows=torch.zeros(1, dtype=torch.int32, device=dev))
+            if W > 1:
+                buf["rec_all"] = torch.empty((m_local * W, dw), dtype=torch.int32, device=dev)
+                buf["dst_all"] = torch.empty(m_local * W, dtype=torch.int32, device=dev)
+            self._sparse_buf = buf
+        st = self._stream()
+        buf["dst"].fill_(-1)
+        if dev_batch.shape[1] < stride * (1 + n_neg):
+            raise KgeError("sparse step: batch buffer smaller than the record stride")
+        _lib.check(self.lib.kge_transe_emit_records(
+            ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(),
+            dev_batch[0].data_ptr(), dev_batch[1].data_ptr(), dev_batch[2].data_ptr(), n_pos, n_neg,
+            dev_batch.shape[1] // (1 + n_neg), denom, buf["rec"].data_ptr(), buf["dst"].data_ptr(), None, None,
+            self._loss.data_ptr(), st), self.lib)
+        if check_shape:
+            nd = ctypes.c_int32(0)
+            _lib.check(self.lib.kge_transe_deferred_groups(ctypes.byref(nd)), self.lib)
+            if nd.value:
+                raise KgeError("sparse_rows: %d groups have negatives that are not single-slot corruptions of their "
+                               "positive; train such batches with sparse_rows=False" % nd.value)
+        if W > 1:
+            allgather_records(buf["rec"], buf["dst"], buf["rec_all"], buf["dst_all"], self._pg)
+            allreduce_gradients([self._loss], self._pg)
+            rec, dst = buf["rec_all"], buf["dst_all"]
+        else:
+            rec, dst = buf["rec"], buf["dst"]
+        _lib.check(self.lib.kge_transe_reduce_records(
+            ctypes.byref(self._desc), rec.data_ptr(), dst.data_ptr(), dst.numel(), buf["rows"].data_ptr(),
+            buf["row_counts"].data_ptr(), buf["n_rows"].data_ptr(), st), self.lib)
+        _lib.check(self.lib.kge_transe_apply_rows_sgd(
+            ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(), buf["rows"].data_ptr(),
+            buf["row_counts"].data_ptr(), buf["n_rows"].data_ptr(), dst.numel(), denom, float(self.alpha), st),
+            self.lib)
+        self.global_step += 1
+
+    def sparse_row_gradients(self):
+        """(rows int32[n], counts int32[n, D]) of the last sparse step: the touched rows (entity rows first, relation
+        rows offset by entTotal) and their integer sign counts."""
+        n = int(self._sparse_buf["n_rows"].item())
+        return self._sparse_buf["rows"][:n], self._sparse_buf["row_counts"][:n]
 
     def forward_counts(self, dev_batch, n_pos, stride, denom):
         """TransE sign-count forward/backward: exact int32 gradient counts -> self._counts."""

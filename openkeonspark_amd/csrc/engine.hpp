@@ -49,6 +49,7 @@ struct Engine {
     int device_state = 0;  // 0 unknown, 1 ok, -1 none
     int time_emit = 0;          // record HIP events around the TransE emit kernel (kge_last_kernel_ms)
     hipEvent_t ev_emit0 = nullptr, ev_emit1 = nullptr;
+    int64_t inv_table_max_bytes = int64_t(256) << 20;  // TransE emit: per-row inverse-norm table only while the tables are this small
     int counts_force_sort = 0;  // test hook: take the sort+segsum reduction even for small tables
 };
 

@@ -560,7 +560,7 @@ __device__ __forceinline__ uint32_t bytes_of(s16x2 lo, s16x2 hi) {
     return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
 }
 
-template <int L, int Q, int K, int WPE>
+template <int L, int Q, int K, int WPE, bool INV_TAB>
 __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
     constexpr int TEAMS = 256 / L;
     __shared__ float red[TEAMS];
@@ -601,8 +601,12 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
             }
             continue;
         }
-        // f = +1/|x| for a new head or relation vector, -1/|x| for a new tail (e = f*x + B)
-        if (lane < (int)a.n_neg) { const float iv = my_code == 2 ? inv_rel[my_row] : inv_ent[my_row]; my_f = my_code == 1 ? -iv : iv; }
+        // f = +1/|x| for a new head or relation vector, -1/|x| for a new tail (e = f*x + B).  With the
+        // per-row table (small tables) it is known before the row arrives; without it (tables too large to
+        // sweep every step) it is computed from the gathered row, one extra team reduction per negative.
+        if constexpr (INV_TAB) {
+            if (lane < (int)a.n_neg) { const float iv = my_code == 2 ? inv_rel[my_row] : inv_ent[my_row]; my_f = my_code == 1 ? -iv : iv; }
+        }
         // ---- the positive: B0 = r^-t^, B1 = h^+r^, B2 = h^-t^ ----
         float4 B0[Q], B1[Q], B2[Q];
         float p;
@@ -610,7 +614,17 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
         {
             float4 hn[Q], tn[Q], rn[Q];
             load4(a.ent, h, hn); load4(a.ent, t, tn); load4(a.rel, r, rn);
-            const float ih = inv_ent[h], it = inv_ent[t], ir = inv_rel[r];
+            float ih, it, ir;
+            if constexpr (INV_TAB) { ih = inv_ent[h]; it = inv_ent[t]; ir = inv_rel[r]; }
+            else {
+                auto ssq = [&](const float4 (&x)[Q]) { float q2 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < Q; q++) q2 += x[q].x * x[q].x + x[q].y * x[q].y + x[q].z * x[q].z + x[q].w * x[q].w;
+                    return q2; };
+                float sh = team_sum<L>(ssq(hn)), st = team_sum<L>(ssq(tn)), sr = team_sum<L>(ssq(rn));
+                ih = 1.0f / sqrtf(sh >= 1e-12f ? sh : 1e-12f); it = 1.0f / sqrtf(st >= 1e-12f ? st : 1e-12f);
+                ir = 1.0f / sqrtf(sr >= 1e-12f ? sr : 1e-12f);
+            }
             float acc = 0.f;
 #pragma unroll
             for (int q = 0; q < Q; q++) {
@@ -641,8 +655,10 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
                     const NegClass nc = classify_negative<KGE_TRANSE>(h, t, r, nh, nt, nr, a.negative_rel);
                     my_code = !nc.same_h ? 0 : (!nc.same_t ? 1 : 2);
                     my_row = !nc.same_h ? nh : (!nc.same_t ? nt : nr);
-                    const float iv = my_code == 2 ? inv_rel[my_row] : inv_ent[my_row];
-                    my_f = my_code == 1 ? -iv : iv;
+                    if constexpr (INV_TAB) {
+                        const float iv = my_code == 2 ? inv_rel[my_row] : inv_ent[my_row];
+                        my_f = my_code == 1 ? -iv : iv;
+                    }
                 }
             }
             const int in_round = min(L, (int)a.n_neg - k0);
@@ -660,6 +676,22 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
                 }
 #pragma unroll
                 for (int u = 0; u < K; u++) load4(code[u] == 2 ? a.rel : a.ent, row[u], x[u]);  // K gathers in flight
+                if constexpr (!INV_TAB) {
+                    float ss[K];
+#pragma unroll
+                    for (int u = 0; u < K; u++) {
+                        float q2 = 0.f;
+#pragma unroll
+                        for (int q = 0; q < Q; q++) q2 += x[u][q].x * x[u][q].x + x[u][q].y * x[u][q].y + x[u][q].z * x[u][q].z + x[u][q].w * x[u][q].w;
+                        ss[u] = q2;
+                    }
+#pragma unroll
+                    for (int u = 0; u < K; u++) {
+                        ss[u] = team_sum<L>(ss[u]);
+                        const float iv = 1.0f / sqrtf(ss[u] >= 1e-12f ? ss[u] : 1e-12f);
+                        f[u] = code[u] == 1 ? -iv : iv;
+                    }
+                }
                 float sc[K];
 #pragma unroll
                 for (int u = 0; u < K; u++) {
@@ -760,20 +792,31 @@ static void launch_emit(const FbArgs &a, float *d_loss, hipStream_t stream) {
     if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
     if (blocks < 1) blocks = 1;
     if (a.D % 4 == 0) {
-        long long nb = (a.ent_total + a.rel_total + 3) / 4;
-        if (nb > 2048) nb = 2048;
-        hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.ent, a.rel, (long long)a.ent_total,
-                           (long long)a.rel_total, a.D, const_cast<float *>(a.inv_norm));
+        // the per-row inverse-norm table costs one sweep of both tables per step: only while they are
+        // cache-sized (FB15k-237 x 200: 11.8 MB); beyond 256 MB the norms are computed from the gathered rows
+        const bool inv_tab = a.inv_norm != nullptr;
+        if (inv_tab) {
+            long long nb = (a.ent_total + a.rel_total + 3) / 4;
+            if (nb > 2048) nb = 2048;
+            hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.ent, a.rel, (long long)a.ent_total,
+                               (long long)a.rel_total, a.D, const_cast<float *>(a.inv_norm));
+        }
         Engine &eng = engine();
         if (eng.time_emit) {   // HIP events around THE kernel, on its launch stream (bench.py roofline)
             if (!eng.ev_emit0) { (void)hipEventCreate(&eng.ev_emit0); (void)hipEventCreate(&eng.ev_emit1); }
             (void)hipEventRecord(eng.ev_emit0, stream);
         }
-        hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         if (eng.time_emit) (void)hipEventRecord(eng.ev_emit1, stream);
     } else
         hipLaunchKernelGGL((transe_emit_kernel<L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
     // groups with non sampler-shaped negatives: exact fp32 path into the residual accumulators
+    // (no residual accumulators = record-only caller: the groups stay listed, kge_transe_deferred_groups reports them)
+    if (!a.g_ent || !a.g_rel) {
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, a.loss_partials, (int)blocks, a.unit, d_loss);
+        return;
+    }
     FbArgs d = a;
     d.loss_partials = a.loss_partials + blocks;
     hipLaunchKernelGGL((fwdbwd_kernel<KGE_TRANSE, L, C>), dim3(kDeferBlocks), dim3(256), 0, stream, d);
@@ -788,6 +831,16 @@ void transe_team_shape(int D, int &L, int &C) {
     else { L = 64; C = 16; }
 }
 
+static int32_t *g_defer_list = nullptr, *g_defer_count = nullptr;
+static int64_t g_defer_cap = 0;
+
+// groups of the LAST emit launch that were not sampler-shaped (synchronous read of the device counter)
+int transe_deferred_groups(int32_t *out) {
+    *out = 0;
+    if (!g_defer_count) return KGE_OK;
+    return hip_check(hipMemcpy(out, g_defer_count, sizeof(int32_t), hipMemcpyDeviceToHost), "read deferred count");
+}
+
 int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *rel, float *resid_ent, float *resid_rel,
                        const int32_t *d_h, const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
                        int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream) {
@@ -796,8 +849,8 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
         int rc = hip_check(hipMalloc(&e.dev.loss_partials, sizeof(float) * (kMaxLossBlocks + 256)), "alloc loss partials");
         if (rc) return rc;
     }
-    static int32_t *defer_list = nullptr, *defer_count = nullptr;
-    static int64_t defer_cap = 0;
+    int32_t *&defer_list = g_defer_list, *&defer_count = g_defer_count;
+    int64_t &defer_cap = g_defer_cap;
     if (n_pos > defer_cap) {
         if (defer_list) (void)hipFree(defer_list);
         defer_list = nullptr;
@@ -812,7 +865,8 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
     }
     static float *inv_norm = nullptr;
     static int64_t inv_cap = 0;
-    if (m.ent_total + m.rel_total > inv_cap) {
+    const bool use_inv_table = (m.ent_total + m.rel_total) * (int64_t)m.ent_dim * 4 <= e.inv_table_max_bytes;
+    if (use_inv_table && m.ent_total + m.rel_total > inv_cap) {
         if (inv_norm) (void)hipFree(inv_norm);
         inv_norm = nullptr;
         int rc = hip_check(hipMalloc(&inv_norm, sizeof(float) * (size_t)(m.ent_total + m.rel_total)), "alloc row inverse norms");
@@ -820,7 +874,7 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
         inv_cap = m.ent_total + m.rel_total;
     }
     FbArgs a = {};
-    a.inv_norm = inv_norm;
+    a.inv_norm = use_inv_table ? inv_norm : nullptr;
     a.group_list = defer_list; a.group_count = defer_count;
     a.ent = ent; a.rel = rel; a.g_ent = resid_ent; a.g_rel = resid_rel;
     a.bh = d_h; a.bt = d_t; a.br = d_r;

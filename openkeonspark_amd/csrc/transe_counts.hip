@@ -32,6 +32,8 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
                        const int32_t *d_h, const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
                        int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream);
 
+int transe_deferred_groups(int32_t *out);
+
 namespace {
 
 struct CtWork {
@@ -120,7 +122,9 @@ __device__ __forceinline__ void flush_run(int32_t *__restrict__ S, int D, int la
 template <int L, int C, bool NAT>
 __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict__ rec, const int32_t *__restrict__ keys,
                                                      const int32_t *__restrict__ ids, const int32_t *__restrict__ n_valid_p,
-                                                     int32_t *__restrict__ S, int D) {
+                                                     const int32_t *__restrict__ uidx, int32_t *__restrict__ S, int D) {
+    // uidx == nullptr: S is the dense [rows, D] table and a run lands in row `key`;
+    // uidx != nullptr: S is compact, a run lands in row uidx[position of the run] (unique-row index)
     constexpr int TEAMS = 256 / L;
     constexpr int Q = (C + 3) / 4;
     constexpr int RD = L * Q;
@@ -134,16 +138,18 @@ __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict_
 #pragma unroll
     for (int c = 0; c < C; c++) acc[c] = 0;
     int cur = keys[start];
+    int cur_row = uidx ? uidx[start] : cur;
     bool first_run = true;
     constexpr int U = 8;  // records in flight per team
     for (int i0 = 0; i0 < n; i0 += U) {
-        int k[U], id[U];
+        int k[U], id[U], ur[U];
         uint32_t w[U][Q];
 #pragma unroll
         for (int u = 0; u < U; u++) {   // unconditional (clamped) loads: all in flight together
             const int i = min(i0 + u, n - 1);
             k[u] = keys[start + i];
             id[u] = ids[start + i];
+            ur[u] = uidx ? uidx[start + i] : k[u];
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -157,10 +163,11 @@ __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict_
         for (int u = 0; u < U; u++) {
             if (k[u] < 0) break;
             if (k[u] != cur) {
-                flush_run<L, C, NAT>(S, D, lane, cur, acc, first_run);
+                flush_run<L, C, NAT>(S, D, lane, cur_row, acc, first_run);
 #pragma unroll
                 for (int c = 0; c < C; c++) acc[c] = 0;
                 cur = k[u];
+                cur_row = ur[u];
                 first_run = false;
             }
 #pragma unroll
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict_
                 }
         }
     }
-    flush_run<L, C, NAT>(S, D, lane, cur, acc, true);
+    flush_run<L, C, NAT>(S, D, lane, cur_row, acc, true);
 }
 
 
@@ -296,6 +303,39 @@ __global__ __launch_bounds__(256) void bkt_sort_kernel(const int2 *__restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Sparse form (tables too large for a dense [rows, D] count image, and the multi-GPU record exchange):
+// the sorted records are summed into a COMPACT [n_unique, D] image, one row per touched table row.
+// ---------------------------------------------------------------------------------------------
+__global__ void run_flags_kernel(const int32_t *__restrict__ keys, const int32_t *__restrict__ n_valid_p, int M, int32_t *__restrict__ flags) {
+    const int n = n_valid_p[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x)
+        flags[i] = (i < n && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
+}
+
+// uidx1 = inclusive scan of the run-start flags: record i belongs to unique row uidx1[i]-1
+__global__ void unique_rows_kernel(const int32_t *__restrict__ keys, const int32_t *__restrict__ n_valid_p, int32_t *__restrict__ uidx1,
+                                   int32_t *__restrict__ rows_out, int32_t *__restrict__ n_rows_out, int32_t *__restrict__ S, int D) {
+    const int n = n_valid_p[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int u = uidx1[i] - 1;
+        uidx1[i] = u;
+        if (i == 0 || keys[i] != keys[i - 1]) rows_out[u] = keys[i];
+        if (i == n - 1) n_rows_out[0] = u + 1;
+        // rows that a chunk's first / last run touches are accumulated with atomics: clear them first
+        if ((i % CHUNK) == 0 || (i % CHUNK) == CHUNK - 1 || i == n - 1)
+            for (int e = 0; e < D; e++) S[(long long)u * D + e] = 0;
+    }
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) n_rows_out[0] = 0;
+}
+
+// d/dx of the normalised row applied to the integer sign sum: unit * (1/|x|) * (S - x^ <x^,S>), with every
+// operation individually rounded so that the dense and the sparse-row apply kernels agree bit for bit
+__device__ __forceinline__ float count_grad(float unit, float inv, float s, float d, float xn) {
+    return __fmul_rn(__fmul_rn(unit, inv), __fsub_rn(s, __fmul_rn(d, xn)));
+}
+
 // stage 3.  optimizer: 0 = SGD (lr), 1 = Adam (lr = lr_t)
 struct ApplyArgs {
     float *p, *m, *v;
@@ -305,48 +345,60 @@ struct ApplyArgs {
     int D;
     float unit, lr, b1, b2, eps;
     int adam;
+    // sparse-row form: S is the compact [n_rows, D] image of the rows listed in row_list (one row space:
+    // entity rows, then relation rows at E + r, which live in table p2); SGD only, no residuals
+    const int32_t *row_list, *n_rows;
+    float *p2;
+    long long E;
 };
 
-template <int L, int C>
+template <int L, int C, bool SPARSE>
 __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
     constexpr int TEAMS = 256 / L;
     Team<L, C> tm;
     tm.lane = threadIdx.x % L;
     tm.D = a.D;
-    for (long long row = (long long)blockIdx.x * TEAMS + threadIdx.x / L; row < a.rows; row += (long long)gridDim.x * TEAMS) {
-        int32_t *Sp = a.S + row * a.D;
-        float *rp = a.resid + row * a.D;
+    const long long n_rows = SPARSE ? (long long)a.n_rows[0] : a.rows;
+    for (long long i = (long long)blockIdx.x * TEAMS + threadIdx.x / L; i < n_rows; i += (long long)gridDim.x * TEAMS) {
+        long long row = i;
+        float *table = a.p;
+        if (SPARSE) {
+            row = a.row_list[i];
+            if (row >= a.E) { row -= a.E; table = a.p2; }
+        }
+        int32_t *Sp = a.S + i * a.D;
+        float *rp = SPARSE ? nullptr : a.resid + row * a.D;
         float s[C], rs[C];
         float touched = 0.f;
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const int e = tm.lane + L * c;
             const int si = e < a.D ? Sp[e] : 0;
-            rs[c] = e < a.D ? rp[e] : 0.f;
+            rs[c] = (!SPARSE && e < a.D) ? rp[e] : 0.f;
             s[c] = (float)si;
             touched += (si != 0 || rs[c] != 0.f) ? 1.f : 0.f;
         }
         touched = team_sum<L>(touched);
         if (touched == 0.f && !a.adam) continue;  // SGD leaves untouched rows alone; TF1 Adam moves every row
         float x[C], g[C];
-        tm.load(a.p, row, x);
+        tm.load(table, row, x);
         if (touched != 0.f) {
             float xn[C], inv; bool uc;
             tm.normalize(x, xn, inv, uc);
             float d = tm.dot(xn, s);
             if (!uc) d = 0.f;
 #pragma unroll
-            for (int c = 0; c < C; c++) g[c] = a.unit * inv * (s[c] - d * xn[c]) + rs[c];
+            for (int c = 0; c < C; c++) g[c] = __fadd_rn(count_grad(a.unit, inv, s[c], d, xn[c]), rs[c]);
         } else {
 #pragma unroll
             for (int c = 0; c < C; c++) g[c] = 0.f;
         }
-        float *pp = a.p + row * a.D;
+        float *pp = table + row * a.D;
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const int e = tm.lane + L * c;
             if (e >= a.D) continue;
-            if (a.adam) {
+            if (!SPARSE && a.adam) {
                 float *mp = a.m + row * a.D + e, *vp = a.v + row * a.D + e;
                 float mi = __fmul_rn(*mp, a.b1), vi = __fmul_rn(*vp, a.b2);
                 if (g[c] != 0.f) {
@@ -356,9 +408,9 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
                 *mp = mi; *vp = vi;
                 pp[e] = __fsub_rn(x[c], __fdiv_rn(__fmul_rn(a.lr, mi), __fadd_rn(__fsqrt_rn(vi), a.eps)));
             } else if (g[c] != 0.f) {
-                pp[e] = x[c] - a.lr * g[c];
+                pp[e] = __fsub_rn(x[c], __fmul_rn(a.lr, g[c]));
             }
-            if (touched != 0.f) { Sp[e] = 0; if (rs[c] != 0.f) rp[e] = 0.f; }
+            if (!SPARSE && touched != 0.f) { Sp[e] = 0; if (rs[c] != 0.f) rp[e] = 0.f; }
         }
     }
 }
@@ -430,9 +482,9 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
         const long long chunks = (M + CHUNK - 1) / CHUNK;                                                             \
         const long long nb = (chunks + (256 / LL) - 1) / (256 / LL);                                                  \
         if (nat) hipLaunchKernelGGL((segsum_kernel<LL, CC, true>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,  \
-                                    g_c.dst_sorted, g_c.ids_sorted, n_valid_p, d_counts, D);                          \
+                                    g_c.dst_sorted, g_c.ids_sorted, n_valid_p, nullptr, d_counts, D);                 \
         else hipLaunchKernelGGL((segsum_kernel<LL, CC, false>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,     \
-                                g_c.dst_sorted, g_c.ids_sorted, n_valid_p, d_counts, D);                              \
+                                g_c.dst_sorted, g_c.ids_sorted, n_valid_p, nullptr, d_counts, D);                     \
     }
         KGE_SHAPE_DISPATCH(D, KGE_SEG2)
 #undef KGE_SEG2
@@ -452,13 +504,111 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
         const long long chunks = (M + CHUNK - 1) / CHUNK;                                                             \
         const long long nb = (chunks + (256 / LL) - 1) / (256 / LL);                                                  \
         if (nat) hipLaunchKernelGGL((segsum_kernel<LL, CC, true>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,  \
-                                    g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, d_counts, D);                        \
+                                    g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, nullptr, d_counts, D);               \
         else hipLaunchKernelGGL((segsum_kernel<LL, CC, false>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,     \
-                                g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, d_counts, D);                            \
+                                g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, nullptr, d_counts, D);                   \
     }
     KGE_SHAPE_DISPATCH(D, KGE_SEG)
 #undef KGE_SEG
     return hip_check(hipGetLastError(), "counts reduce launch");
+}
+
+INT kge_transe_record_dwords(const kge_model_desc *m) {
+    if (!m) return 0;
+    int L, C;
+    transe_team_shape(m->ent_dim, L, C);
+    return (INT)L * ((C + 3) / 4);
+}
+
+int kge_transe_emit_records(const kge_model_desc *m, const float *d_ent, const float *d_rel, const int32_t *d_h, const int32_t *d_t,
+                            const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom, uint32_t *d_rec, int32_t *d_dst,
+                            float *d_resid_ent, float *d_resid_rel, float *d_loss, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_emit_records: no usable HIP device");
+    if (!m || !kge_transe_counts_supported(m, n_neg)) return fail(KGE_ERR_UNSUPPORTED, "sign-count path: TransE, dim <= 1024, 1..63 negatives");
+    if (n_pos < 0 || stride < n_pos || denom <= 0 || !d_rec || !d_dst) return fail(KGE_ERR_BAD_ARG, "kge_transe_emit_records: bad arguments");
+    if (n_pos == 0) return hip_check(hipMemsetAsync(d_loss, 0, sizeof(float), stream), "zero loss");
+    return launch_transe_emit(*m, d_ent, d_rel, d_resid_ent, d_resid_rel, d_h, d_t, d_r, n_pos, n_neg, stride, denom, d_rec, d_dst, 1,
+                              d_loss, stream);
+}
+
+int kge_transe_deferred_groups(int32_t *n_groups) {
+    if (!n_groups) return fail(KGE_ERR_BAD_ARG, "kge_transe_deferred_groups: null output");
+    return transe_deferred_groups(n_groups);
+}
+
+int kge_transe_reduce_records(const kge_model_desc *m, const uint32_t *d_rec, int32_t *d_dst, INT n_records, int32_t *d_rows,
+                              int32_t *d_row_counts, int32_t *d_n_rows, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_reduce_records: no usable HIP device");
+    if (!m || !d_rec || !d_dst || !d_rows || !d_row_counts || !d_n_rows || n_records < 0 || n_records >= (INT(1) << 31))
+        return fail(KGE_ERR_BAD_ARG, "kge_transe_reduce_records: bad arguments");
+    if (n_records == 0) return hip_check(hipMemsetAsync(d_n_rows, 0, sizeof(int32_t), stream), "zero n_rows");
+    int L, C;
+    transe_team_shape(m->ent_dim, L, C);
+    const int64_t M = n_records;
+    int rc = ensure_counts_work(M, (size_t)L * ((C + 3) / 4));
+    if (rc) return rc;
+    const int rows = (int)(m->ent_total + m->rel_total);
+    const int D = m->ent_dim;
+    const bool nat = D % 4 == 0;
+    int blocks = (int)((M + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    // order (row, record id) pairs by row: rocPRIM radix sort handles any row space
+    hipLaunchKernelGGL(fix_keys_kernel, dim3(blocks), dim3(256), 0, stream, d_dst, (long long)M, rows);
+    size_t tmp = g_c.sort_tmp_bytes;
+    rc = hip_check(rocprim::radix_sort_pairs(g_c.sort_tmp, tmp, d_dst, g_c.dst_sorted, g_c.ids, g_c.ids_sorted, (size_t)M, 0,
+                                             bits_for_rows(rows), stream), "records sort");
+    if (rc) return rc;
+    hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(64), 0, stream, g_c.dst_sorted, (int)M, rows, g_c.n_valid);
+    // unique-row index of every record (flags -> inclusive scan), row list, boundary rows cleared
+    int32_t *uidx = g_c.pairs;   // [M] scratch
+    hipLaunchKernelGGL(run_flags_kernel, dim3(blocks), dim3(256), 0, stream, g_c.dst_sorted, g_c.n_valid, (int)M, uidx);
+    size_t scan_bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, scan_bytes, uidx, uidx, (size_t)M, rocprim::plus<int32_t>(), stream);
+    if (scan_bytes > g_c.sort_tmp_bytes) {
+        if (g_c.sort_tmp) (void)hipFree(g_c.sort_tmp);
+        g_c.sort_tmp = nullptr;
+        if ((rc = hip_check(hipMalloc(&g_c.sort_tmp, scan_bytes), "scan temp"))) return rc;
+        g_c.sort_tmp_bytes = scan_bytes;
+    }
+    rc = hip_check(rocprim::inclusive_scan(g_c.sort_tmp, scan_bytes, uidx, uidx, (size_t)M, rocprim::plus<int32_t>(), stream), "run scan");
+    if (rc) return rc;
+    hipLaunchKernelGGL(unique_rows_kernel, dim3(blocks), dim3(256), 0, stream, g_c.dst_sorted, g_c.n_valid, uidx, d_rows, d_n_rows,
+                       d_row_counts, D);
+#define KGE_SEGC(LL, CC)                                                                                              \
+    {                                                                                                                 \
+        const long long chunks = (M + CHUNK - 1) / CHUNK;                                                             \
+        const long long nb = (chunks + (256 / LL) - 1) / (256 / LL);                                                  \
+        if (nat) hipLaunchKernelGGL((segsum_kernel<LL, CC, true>), dim3((unsigned)nb), dim3(256), 0, stream, d_rec,    \
+                                    g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, uidx, d_row_counts, D);              \
+        else hipLaunchKernelGGL((segsum_kernel<LL, CC, false>), dim3((unsigned)nb), dim3(256), 0, stream, d_rec,       \
+                                g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, uidx, d_row_counts, D);                  \
+    }
+    KGE_SHAPE_DISPATCH(D, KGE_SEGC)
+#undef KGE_SEGC
+    return hip_check(hipGetLastError(), "records reduce launch");
+}
+
+int kge_transe_apply_rows_sgd(const kge_model_desc *m, float *d_ent, float *d_rel, const int32_t *d_rows, const int32_t *d_row_counts,
+                              const int32_t *d_n_rows, INT max_rows, INT denom, float lr, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_apply_rows_sgd: no usable HIP device");
+    if (!m || !d_rows || !d_row_counts || !d_n_rows || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_rows_sgd: bad arguments");
+    if (max_rows <= 0) return KGE_OK;
+    ApplyArgs a = {};
+    a.p = d_ent; a.p2 = d_rel; a.row_list = d_rows; a.S = const_cast<int32_t *>(d_row_counts); a.n_rows = d_n_rows;
+    a.E = m->ent_total; a.D = m->ent_dim; a.unit = 1.0f / (float)denom; a.lr = lr; a.adam = 0;
+    const int D = m->ent_dim;
+#define KGE_RAPPLY(LL, CC)                                                                                  \
+    {                                                                                                       \
+        long long nb = (max_rows + (256 / LL) - 1) / (256 / LL);                                            \
+        if (nb > 8192) nb = 8192;                                                                           \
+        hipLaunchKernelGGL((apply_counts_kernel<LL, CC, true>), dim3((unsigned)nb), dim3(256), 0, stream, a); \
+    }
+    KGE_SHAPE_DISPATCH(D, KGE_RAPPLY)
+#undef KGE_RAPPLY
+    return hip_check(hipGetLastError(), "apply rows launch");
 }
 
 int kge_transe_apply_counts(float *d_p, float *d_m, float *d_v, int32_t *d_counts, float *d_resid, int64_t rows, int32_t dim,
@@ -475,7 +625,7 @@ int kge_transe_apply_counts(float *d_p, float *d_m, float *d_v, int32_t *d_count
     {                                                                                                       \
         long long nb = (rows + (256 / LL) - 1) / (256 / LL);                                                \
         if (nb > 4096) nb = 4096;                                                                           \
-        hipLaunchKernelGGL((apply_counts_kernel<LL, CC>), dim3((unsigned)nb), dim3(256), 0, stream, a);     \
+        hipLaunchKernelGGL((apply_counts_kernel<LL, CC, false>), dim3((unsigned)nb), dim3(256), 0, stream, a); \
     }
     KGE_SHAPE_DISPATCH(D, KGE_APPLY)
 #undef KGE_APPLY

@@ -47,3 +47,29 @@ def allreduce_gradients(tensors, group=None):
     works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in tensors]
     for w in works:
         w.wait()
+
+
+def max_slice_positions(lib, batch_size, world_size, work_threads):
+    """Largest number of batch positions any rank owns (Base.cpp:85-92 slices grouped by rank)."""
+    import ctypes
+    best = 0
+    for g in range(world_size):
+        lo, hi = thread_range(g, world_size, work_threads)
+        first = ctypes.c_int64(0)
+        best = max(best, int(lib.kge_slice_positions(batch_size, lo, hi, ctypes.byref(first))))
+    return max(best, 1)
+
+
+def allgather_records(rec, dst, rec_all, dst_all, process_group=None):
+    """Sparse gradient exchange: every rank receives every rank's int8 sign records and their destination rows
+    (rank-major order; integer sums downstream make the result independent of that order)."""
+    import torch
+    import torch.distributed as dist
+    for src, out in ((rec, rec_all), (dst, dst_all)):
+        if src.is_cuda and dist.get_backend(process_group) == "gloo":
+            # gloo has no device all-gather: stage through the host (test rigs only; RCCL gathers in HBM)
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, src.cpu(), group=process_group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, src, group=process_group)

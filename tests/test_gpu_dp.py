@@ -12,7 +12,7 @@ from conftest import GOLDEN, ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir, model_name, opt):
+def _worker(rank, world, port, out_dir, model_name, opt, sparse=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -25,8 +25,10 @@ def _worker(rank, world, port, out_dir, model_name, opt):
     con.set_in_path(os.path.join(GOLDEN, "kg_small"))
     con.set_work_threads(8); con.set_bern(1); con.set_dimension(48); con.set_nbatches(10)  # B = 600
     con.set_ent_neg_rate(3); con.set_alpha(0.02); con.set_opt_method(opt)
+    con.sparse_rows = sparse
     con.init()
     con.set_model_and_session(getattr(pkg, model_name))
+    assert con.sparse_rows == sparse
     if world > 1:
         con.init_distributed()
     losses = [con.train_step() for _ in range(4)]
@@ -55,3 +57,22 @@ def test_two_ranks_equal_single_process(tmp_path, model_name, opt):
         assert np.array_equal(r0[k], r1[k]), k  # replicas apply the identical all-reduced update
         tol = 2e-5 if opt == "SGD" else 2e-4
         assert np.abs(r0[k] - one[k]).max() <= tol * np.abs(one[k]).max(), k
+
+
+def test_two_ranks_sparse_record_exchange(tmp_path):
+    """Sparse-row mode: the ranks all-gather their int8 records; integer sums make the replicas' tables equal
+    to the single-process tables bit for bit."""
+    import torch.multiprocessing as mp
+    port = 29700 + os.getpid() % 1000
+    mp.start_processes(_worker, args=(1, port, str(tmp_path), "TransE", "SGD", True), nprocs=1, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(2, port + 1, str(tmp_path), "TransE", "SGD", True), nprocs=2, join=True, start_method="spawn")
+    one = np.load(str(tmp_path / "w1_r0.npz"))
+    r0 = np.load(str(tmp_path / "w2_r0.npz"))
+    r1 = np.load(str(tmp_path / "w2_r1.npz"))
+    assert np.array_equal(r0["states"], one["states"]) and np.array_equal(r1["states"], one["states"])
+    assert np.allclose(r0["losses"], one["losses"], rtol=2e-5, atol=0)
+    for k in one.files:
+        if k in ("losses", "states"):
+            continue
+        assert np.array_equal(r0[k], r1[k]), k
+        assert np.array_equal(r0[k], one[k]), k

@@ -1,0 +1,102 @@
+"""Sparse-row TransE path (stage-level C ABI: emit records -> compact per-row counts -> row SGD) against the
+dense count image and the oracle.  Integer sums: the two engine paths must agree bit for bit."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def make_config(kg, dim, n_neg, sparse, nbatches=4, threads=4, seed=7):
+    import torch
+    import openkeonspark_amd as ok
+    con = ok.Config()
+    con.set_in_path(os.path.join(GOLD, kg) + "/")
+    con.set_work_threads(threads)
+    con.set_nbatches(nbatches)
+    con.set_alpha(0.05)
+    con.set_margin(1.0)
+    con.set_bern(1)
+    con.set_dimension(dim)
+    con.set_ent_neg_rate(n_neg)
+    con.set_rel_neg_rate(0)
+    con.set_opt_method("SGD")
+    con.sparse_rows = sparse
+    con.init()
+    torch.manual_seed(seed)
+    con.set_model_and_session(ok.TransE)
+    return con
+
+
+@pytest.mark.parametrize("dim,n_neg", [(16, 1), (50, 3), (200, 25), (512, 2)])
+@pytest.mark.parametrize("inv_table", [True, False])
+def test_sparse_equals_dense_counts(dim, n_neg, inv_table):
+    import torch
+    import openkeonspark_amd as ok
+    from openkeonspark_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.kge_set_option(b"libc_rand_restart", 1), lib)
+    _lib.check(lib.kge_set_option(b"inv_table_max_bytes", (256 << 20) if inv_table else 0), lib)
+    try:
+        dense = make_config("kg_small", dim, n_neg, sparse=False)
+        assert dense.use_counts and not dense.sparse_rows
+        p0 = [t.clone() for t in dense._tables]
+        losses_d = [dense.train_step() for _ in range(6)]
+        _lib.check(lib.kge_set_option(b"libc_rand_restart", 1), lib)
+        sparse = make_config("kg_small", dim, n_neg, sparse=True)
+        assert sparse.sparse_rows and sparse._grads == []
+        for t, q in zip(sparse._tables, p0):
+            t.copy_(q)
+        losses_s = [sparse.train_step() for _ in range(6)]
+    finally:
+        _lib.check(lib.kge_set_option(b"inv_table_max_bytes", 256 << 20), lib)
+    assert losses_d == losses_s
+    for a, b in zip(dense._tables, sparse._tables):
+        assert torch.equal(a, b)
+    rows, counts = sparse.sparse_row_gradients()
+    rows = rows.cpu().numpy()
+    assert len(rows) > 0 and np.all(np.diff(rows) > 0) and rows.max() < sparse.entTotal + sparse.relTotal
+
+
+def test_sparse_row_counts_match_dense_image():
+    """The compact image is the dense image restricted to its touched rows."""
+    import torch
+    from openkeonspark_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.kge_set_option(b"libc_rand_restart", 1), lib)
+    dense = make_config("kg_tiny", 64, 4, sparse=False, nbatches=2, threads=2)
+    dev, n_pos = dense.sample_device()
+    stride = max(dense._n_local, 1)
+    denom = dense.batch_size * 4
+    dense.forward_counts(dev, n_pos, stride, denom)
+    image = dense._counts.clone()
+    _lib.check(lib.kge_set_option(b"libc_rand_restart", 1), lib)
+    sparse = make_config("kg_tiny", 64, 4, sparse=True, nbatches=2, threads=2)
+    for t, q in zip(sparse._tables, dense._tables):
+        t.copy_(q)
+    sparse.set_alpha(0.0)   # keep the tables: only the reduction is under test
+    sparse.train_step()
+    rows, counts = sparse.sparse_row_gradients()
+    touched = torch.zeros(image.shape[0], dtype=torch.bool, device=image.device)
+    touched[rows.long()] = True
+    assert torch.equal(image[rows.long()], counts)
+    assert int(image[~touched].abs().sum()) == 0
+
+
+def test_sparse_rejects_unshaped_host_batch():
+    import openkeonspark_amd as ok
+    con = make_config("kg_tiny", 32, 1, sparse=True, nbatches=2, threads=1)
+    n = 8
+    h = np.arange(n, dtype=np.int64) % con.entTotal
+    t = (np.arange(n, dtype=np.int64) + 3) % con.entTotal
+    r = np.zeros(n, dtype=np.int64)
+    # negatives that change head AND tail: not single-slot corruptions
+    bh = np.concatenate([h, (h + 1) % con.entTotal])
+    bt = np.concatenate([t, (t + 1) % con.entTotal])
+    br = np.concatenate([r, r])
+    with pytest.raises(ok.KgeError):
+        con.train_step(bh, bt, br, None)

@@ -63,3 +63,40 @@ def test_thread_range_requires_divisibility():
     assert thread_range(7, 8, 8) == (7, 8)
     with pytest.raises(ValueError):
         thread_range(0, 3, 8)
+
+
+def _records_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from openkeonspark_amd import _lib
+    from openkeonspark_amd.parallel import allgather_records, max_slice_positions, thread_range, slice_positions
+    lib = _lib.load()
+    W, B, dw = 6, 100, 4            # 100 % 6 != 0: ragged slices, ranks own 51 and 49 positions
+    lib.setWorkThreads(W)
+    m = max_slice_positions(lib, B, world, W)
+    lo, hi = thread_range(rank, world, W)
+    first, cnt = slice_positions(B, W, lo, hi)
+    assert cnt <= m
+    rec = torch.full((m, dw), -1, dtype=torch.int32)
+    dst = torch.full((m,), -1, dtype=torch.int32)
+    dst[:cnt] = torch.arange(first, first + cnt, dtype=torch.int32)   # record i of the global batch
+    rec[:cnt] = dst[:cnt, None] * 10 + torch.arange(dw, dtype=torch.int32)
+    rec_all = torch.empty((m * world, dw), dtype=torch.int32)
+    dst_all = torch.empty(m * world, dtype=torch.int32)
+    allgather_records(rec, dst, rec_all, dst_all)
+    np.savez(os.path.join(out_dir, "rec%d.npz" % rank), rec=rec_all.numpy(), dst=dst_all.numpy(), m=m)
+    dist.destroy_process_group()
+
+
+def test_record_allgather_covers_every_position_once(tmp_path):
+    """The sparse exchange: equal-sized padded record blocks, every global batch position exactly once."""
+    port = 31500 + os.getpid() % 2000
+    mp.start_processes(_records_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    z0, z1 = np.load(str(tmp_path / "rec0.npz")), np.load(str(tmp_path / "rec1.npz"))
+    assert int(z0["m"]) == 51
+    assert np.array_equal(z0["rec"], z1["rec"]) and np.array_equal(z0["dst"], z1["dst"])
+    live = z0["dst"] >= 0
+    assert sorted(z0["dst"][live].tolist()) == list(range(100))
+    assert np.array_equal(z0["rec"][live], z0["dst"][live][:, None] * 10 + np.arange(4))
