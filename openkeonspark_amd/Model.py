@@ -25,6 +25,25 @@ def xavier_normal(rng, shape):
     return (a * std).astype(np.float32)
 
 
+LARGE_TABLE_ELEMS = 1 << 28   # beyond 1 GiB of fp32 a table is initialised in HBM, never staged on the host
+
+
+def xavier_normal_device(shape, device, seed):
+    """Same distribution as xavier_normal, drawn by the device generator in row blocks (a 50M x 512
+    table is 102 GB: it exists only in HBM)."""
+    import torch
+    rows, cols = shape
+    std = float(np.sqrt(2.6 / (rows + cols)))
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    block = max(1, (1 << 27) // max(cols, 1))
+    for r0 in range(0, rows, block):
+        part = out[r0:r0 + block]
+        torch.nn.init.trunc_normal_(part, 0.0, std, -2.0 * std, 2.0 * std, generator=gen)   # inverse-CDF draw, in place
+    return out
+
+
 class Model(object):
     model_id = None       # _lib.TRANSE ...
     table_names = ()      # engine table order (include/kge_mi355.h)
@@ -58,7 +77,10 @@ class Model(object):
         self.parameter_lists = {}
         for name in self.table_names:
             shape = self.table_shapes()[name]
-            self.parameter_lists[name] = torch.from_numpy(xavier_normal(rng, shape)).to(device)
+            if int(np.prod(shape)) > LARGE_TABLE_ELEMS:
+                self.parameter_lists[name] = xavier_normal_device(shape, device, getattr(config, "seed", 0))
+            else:
+                self.parameter_lists[name] = torch.from_numpy(xavier_normal(rng, shape)).to(device)
         for name, t in self.parameter_lists.items():
             setattr(self, name, t)
 

@@ -1,0 +1,70 @@
+"""Rehearsal of BASELINE config #5 (synthetic KG, 50M entities, TransE dim 512, sparse touched-row exchange) on
+ONE GPU: the full-size entity table (102 GB) lives in HBM, the triple count is scaled to what the host can index
+in the time a gpurun call allows.  Prints one JSON line; `--profile-steps` keeps the run short under rocprofv3."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--entities", type=int, default=50_000_000)
+    ap.add_argument("--relations", type=int, default=1000)
+    ap.add_argument("--triples", type=int, default=20_000_000)
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=200_000)
+    ap.add_argument("--neg", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--ent-exponent", type=float, default=0.8, help="Zipf exponent of entity popularity (0 = uniform)")
+    ap.add_argument("--dense", action="store_true", help="dense count image instead of the sparse-row path")
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+    import openkeonspark_amd as ok
+    from openkeonspark_amd.synthetic import generate_triples
+    t0 = time.time()
+    h, t, r = generate_triples(a.entities, a.relations, a.triples, seed=5, dup_frac=0.0, ent_exponent=a.ent_exponent)
+    t_gen = time.time() - t0
+    con = ok.Config()
+    con.set_work_threads(a.threads)
+    con.set_bern(1)
+    con.set_dimension(a.dim)
+    con.set_ent_neg_rate(a.neg)
+    con.set_rel_neg_rate(0)
+    con.set_alpha(0.01)
+    con.set_margin(1.0)
+    con.set_opt_method("SGD")
+    con.set_nbatches(max(1, a.triples // a.batch))
+    con.sparse_rows = not a.dense
+    t0 = time.time()
+    con.init_from_arrays(a.entities, a.relations, h, t, r)
+    t_index = time.time() - t0
+    del h, t, r
+    t0 = time.time()
+    con.set_model_and_session(ok.TransE)
+    torch.cuda.synchronize()
+    t_init = time.time() - t0
+    for _ in range(a.warmup):
+        con.train_step(sync=False)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(a.steps):
+        loss = con.train_step(sync=False)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    B = con.batch_size
+    print(json.dumps({"workload": "synthetic KG %dM entities / %dM triples TransE dim=%d SGD %d neg/pos, %s" % (
+        a.entities // 1_000_000, a.triples // 1_000_000, a.dim, a.neg, "dense image" if a.dense else "sparse rows"),
+        "ent_exponent": a.ent_exponent, "batch": B, "ms_per_step": 1e3 * dt / a.steps, "positives_per_s": B * a.steps / dt, "loss": float(loss.item()),
+        "hbm_allocated_GB": torch.cuda.max_memory_allocated() / 1e9,
+        "seconds": {"generate": round(t_gen, 1), "index": round(t_index, 1), "table_init": round(t_init, 1)}}))
+
+
+if __name__ == "__main__":
+    main()
