@@ -112,6 +112,9 @@ const char *kge_version(void);
  *   "inv_table_max_bytes": the TransE emit kernel reads 1/|row| from a per-row table rebuilt every step while
  *                        the two tables are at most this many bytes (default 256 MiB); larger tables (or 0)
  *                        compute the norms from the gathered rows
+ *   "float_records":     1 (default) = kge_forward_backward stores TransE/H/D gradient rows as records and sums
+ *                        them by destination after a sort; 0 = fp32 atomic adds straight into the accumulators
+ *   "float_records_min": smallest number of gradient rows per step that takes the record path (default 65536: measured cross-over, tools/sweep_paths.py)
  *   "time_emit":         1 = bracket the TransE emit kernel with HIP events on its launch stream
  *   "libc_rand_restart": restart the glibc-compatible seed generator, as in a fresh process (the next
  *                        randReset then yields 1804289383, 846930886, ... again) */

@@ -283,6 +283,10 @@ class Config(object):
         self.prefetch_sampling = bool(getattr(self, "prefetch_sampling", False))  # measured: no gain at 1 GPU (the sampler competes with segsum/apply)
         self.global_step = 0
         self._sparse_buf = None
+        # TransE steps with fewer gradient rows than this take the single fused fp32-atomic kernel (launch-bound
+        # regime, tools/sweep_paths.py); 0 = always the exact, run-to-run reproducible count pipeline
+        self.counts_min_records = int(getattr(self, "counts_min_records",
+                                              os.environ.get("KGE_COUNTS_MIN_RECORDS", 1 << 16)))
         if self.use_counts and not self.sparse_rows:
             self._counts = torch.zeros((self.entTotal + self.relTotal, self.hidden_size), dtype=torch.int32,
                                        device=self.device)
@@ -404,11 +408,14 @@ class Config(object):
             n_pos = host.shape[1] // (1 + n_neg)
             stride = n_pos
         denom = self.batch_size * n_neg if batch_h is None else n_pos * n_neg
+        # small steps are launch-bound: the single fused atomic kernel beats the multi-stage count pipeline
+        # (same decision on every rank: it depends on the global batch only)
+        big = (self.batch_size if batch_h is None else n_pos) * (3 + n_neg) >= self.counts_min_records * self.world_size
         if self.sparse_rows:
             self._sparse_step(dev, n_pos, stride, denom, check_shape=batch_h is not None)
             if batch_h is None and self.prefetch_sampling:
                 self._prefetch_next_batch()
-        elif self.use_counts:
+        elif self.use_counts and big:
             self.forward_counts(dev, n_pos, stride, denom)
             if batch_h is None and self.prefetch_sampling:
                 self._prefetch_next_batch()

@@ -202,6 +202,8 @@ int kge_set_option(const char *name, INT value) {
     std::string n = name ? name : "";
     if (n == "counts_force_sort") { engine().counts_force_sort = value != 0; return KGE_OK; }
     if (n == "inv_table_max_bytes") { engine().inv_table_max_bytes = value; return KGE_OK; }
+    if (n == "float_records") { engine().float_records = value != 0; return KGE_OK; }
+    if (n == "float_records_min") { engine().float_records_min = value; return KGE_OK; }
     if (n == "time_emit") { engine().time_emit = value != 0; return KGE_OK; }
     if (n == "libc_rand_restart") { engine().libc = LibcRand(); return KGE_OK; }  // as in a fresh process
     return fail(KGE_ERR_BAD_ARG, "kge_set_option: unknown option " + n);

@@ -50,6 +50,8 @@ struct Engine {
     int time_emit = 0;          // record HIP events around the TransE emit kernel (kge_last_kernel_ms)
     hipEvent_t ev_emit0 = nullptr, ev_emit1 = nullptr;
     int64_t inv_table_max_bytes = int64_t(256) << 20;  // TransE emit: per-row inverse-norm table only while the tables are this small
+    int float_records = 1;              // TransH / TransD (and TransE without counts): record + segmented-sum path instead of fp32 atomics
+    int64_t float_records_min = 1 << 16; // ... from this many gradient rows per step (below it the atomic kernel alone is quicker)
     int counts_force_sort = 0;  // test hook: take the sort+segsum reduction even for small tables
 };
 
@@ -81,6 +83,16 @@ __host__ __device__ inline NegClass classify_negative(long long h, long long t, 
 }
 
 
+
+// float-record reduction (transe_counts.hip): destination row space = up to four tables back to back
+struct FloatRowSpace {   // virtual row space of models.hip's FbArgs::frec records
+    float *g_ent, *g_rel, *g_auxr, *g_auxe;
+    long long E, R;             // entity rows [0,E), ent_transfer rows [E, hub_base) when hub_base == 2E
+    long long hub_base, hub_rows;   // copies of { rel [R] | auxr [R] } from hub_base on, hub_rows rows per copy
+    long long rows;             // total virtual rows
+};
+int float_records_workspace(int64_t M, int D, float *&rec, int32_t *&dst);
+int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t stream);
 
 // ---- launchers implemented in the .hip files ------------------------------------------------
 int launch_sampler(int32_t *d_h, int32_t *d_t, int32_t *d_r, int64_t B, int64_t neg, int64_t negrel, int64_t thread_lo,

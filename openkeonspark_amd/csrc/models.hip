@@ -47,7 +47,30 @@ struct FbArgs {
     int32_t *group_count;
     int debug;  // diagnosis only
     const float *inv_norm;  // [E+R] 1/|row| of ent_embeddings then rel_embeddings, refreshed per step (vectorised emit)
+    // float-record path (TransH / TransD, float_records in transe_counts.hip): instead of an atomic row add, a
+    // gradient row is STORED as record m = slot*n_pos + b with its destination in the VIRTUAL row space
+    //   ent [0,E) | ent_transfer [E,2E) (TransD) | hub_k copies of { rel [R] | normal vectors / rel_transfer [R] }
+    // group b writes its relation-side rows into copy b % hub_k, so that the records of a hub relation (WN18RR has
+    // 11 relations) spread over many sort buckets; the segmented sum folds the copies back onto the real row
+    float *frec;
+    int32_t *fdst;
+    long long hub_base;   // first row of copy 0
+    int hub_k, hub_rows;  // copies, rows per copy (R or 2R)
 };
+
+// one gradient row: atomic add into the dense accumulator, or (REC, m >= 0) a plain 4*D-byte record store
+template <bool REC, int L, int C>
+__device__ __forceinline__ void put_row(const Team<L, C> &tm, const FbArgs &a, float *gtab, long long row, long long vrow, long long m,
+                                        const float (&v)[C]) {
+    if (REC && m >= 0) {
+        float *p = a.frec + m * a.D;
+#pragma unroll
+        for (int c = 0; c < C; c++) { const int e = tm.lane + L * c; if (e < a.D) p[e] = v[c]; }
+        if (tm.lane == 0) a.fdst[m] = (int32_t)vrow;
+    } else {
+        tm.add(gtab, row, v);
+    }
+}
 
 // One entity side (h or t slot) of a scored triple: raw row(s), projected+normalised vector.
 template <int C>
@@ -85,13 +108,14 @@ __device__ __forceinline__ void side_forward(const Team<L, C> &tm, const FbArgs 
 
 // Backward of one entity side given G = dL/d(normalised projected vector).  Adds the row gradient(s)
 // and accumulates the relation-context gradient into acw (TransH: d/dw^, TransD: d/dr_p).
-template <int MODEL, int L, int C>
+// m = record index of the entity row (TransD: its transfer row is the next SLOT, m + n_pos); -1 = atomic add
+template <int MODEL, int L, int C, bool REC = false>
 __device__ __forceinline__ void side_backward(const Team<L, C> &tm, const FbArgs &a, long long row, const Side<C> &s,
-                                              const float (&G)[C], const float (&cw)[C], float (&acw)[C]) {
+                                              const float (&G)[C], const float (&cw)[C], float (&acw)[C], long long m = -1) {
     float gxp[C];
     tm.normalize_bwd(s.nrm, G, s.inv, s.uc, gxp);
     if constexpr (MODEL == KGE_TRANSE) {
-        tm.add(a.g_ent, row, gxp);
+        put_row<REC>(tm, a, a.g_ent, row, row, m, gxp);
     } else if constexpr (MODEL == KGE_TRANSR) {
         tm.store(a.GP, row, gxp);  // each canonical slot is written by exactly one team
     } else if constexpr (MODEL == KGE_TRANSH) {
@@ -99,14 +123,14 @@ __device__ __forceinline__ void side_backward(const Team<L, C> &tm, const FbArgs
         float gx[C];
 #pragma unroll
         for (int c = 0; c < C; c++) { gx[c] = gxp[c] - d * cw[c]; acw[c] -= d * s.raw[c] + s.a * gxp[c]; }
-        tm.add(a.g_ent, row, gx);
+        put_row<REC>(tm, a, a.g_ent, row, row, m, gx);
     } else {
         float d = tm.dot(gxp, cw);
         float gx[C], gv[C];
 #pragma unroll
         for (int c = 0; c < C; c++) { gx[c] = gxp[c] + d * s.aux[c]; gv[c] = d * s.raw[c]; acw[c] += s.a * gxp[c]; }
-        tm.add(a.g_ent, row, gx);
-        tm.add(a.g_auxe, row, gv);
+        put_row<REC>(tm, a, a.g_ent, row, row, m, gx);
+        put_row<REC>(tm, a, a.g_auxe, row, (long long)a.ent_total + row, m >= 0 ? m + a.n_pos : -1, gv);
     }
 }
 
@@ -137,19 +161,32 @@ __device__ __forceinline__ void ctx_forward(const Team<L, C> &tm, const FbArgs &
 }
 
 // Adds the relation-side gradients: Gr = dL/d rn, acw = accumulated dL/d cw.
-template <int MODEL, int L, int C>
+// m = record index of the rel_embeddings row; the context row (normal vector / rel_transfer) is the next slot
+template <int MODEL, int L, int C, bool REC = false>
 __device__ __forceinline__ void ctx_backward(const Team<L, C> &tm, const FbArgs &a, long long r, const Ctx<C> &cx,
-                                             const float (&Gr)[C], const float (&acw)[C]) {
+                                             const float (&Gr)[C], const float (&acw)[C], long long m = -1, long long hub = 0) {
+    // hub = first virtual row of this group's copy of the relation-side rows
     float g[C];
     tm.normalize_bwd(cx.rn, Gr, cx.inv_r, cx.uc_r, g);
-    tm.add(a.g_rel, r, g);
+    put_row<REC>(tm, a, a.g_rel, r, hub + r, m, g);
+    const long long m2 = m >= 0 ? m + a.n_pos : -1;
     if constexpr (MODEL == KGE_TRANSH) {
         tm.normalize_bwd(cx.cw, acw, cx.inv_w, cx.uc_w, g);
-        tm.add(a.g_auxr, r, g);
+        put_row<REC>(tm, a, a.g_auxr, r, hub + a.rel_total + r, m2, g);
     } else if constexpr (MODEL == KGE_TRANSD) {
-        tm.add(a.g_auxr, r, acw);
+        put_row<REC>(tm, a, a.g_auxr, r, hub + a.rel_total + r, m2, acw);
     }
 }
+
+// slot layout of the float-record path (record m = slot*n_pos + b):
+//   TransE: h, t, r, then one slot per negative            (3 + n)
+//   TransH: h, t, r, w, then one slot per negative          (4 + n)
+//   TransD: h, h_p, t, t_p, r, r_p, then two per negative   (6 + 2n)
+template <int MODEL> struct RecSlots {
+    static constexpr int ent_w = MODEL == KGE_TRANSD ? 2 : 1;                 // slots per entity side
+    static constexpr int h = 0, t = ent_w, r = 2 * ent_w;
+    static constexpr int group = 2 * ent_w + (MODEL == KGE_TRANSE ? 1 : 2);   // slots of the positive's shared rows
+};
 
 template <int L, int C>
 __device__ __forceinline__ float l1_score(const Team<L, C> &tm, const float (&hn)[C], const float (&rn)[C],
@@ -207,9 +244,10 @@ __device__ __forceinline__ bool standalone_negative(const Team<L, C> &tm, const 
     return true;
 }
 
-template <int MODEL, int L, int C>
+template <int MODEL, int L, int C, bool REC = false>
 __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
     constexpr int TEAMS = 256 / L;
+    using RS = RecSlots<MODEL>;
     __shared__ float red[TEAMS];
     Team<L, C> tm;
     tm.lane = threadIdx.x % L;
@@ -220,6 +258,7 @@ __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
     for (long long gi = (long long)blockIdx.x * TEAMS + team_in_block; gi < n_groups; gi += (long long)gridDim.x * TEAMS) {
         const long long b = a.group_list ? (long long)a.group_list[gi] : gi;
         const long long h = a.bh[b], t = a.bt[b], r = a.br[b];
+        const long long hub = REC ? a.hub_base + (long long)(b % a.hub_k) * a.hub_rows : 0;
         Ctx<C> cx;
         ctx_forward<MODEL, L, C>(tm, a, r, cx);
         // row handles of the two entity sides: the entity id, or (TransR) the slot of the projected
@@ -243,9 +282,15 @@ __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
             const long long s_neg = (k + 1) * a.n_pos + b;
             const long long nrow_h = MODEL == KGE_TRANSR ? 2 * s_neg : nh;
             const long long nrow_t = MODEL == KGE_TRANSR ? 2 * s_neg + 1 : nt;
+            const long long m_neg = REC ? (RS::group + RS::ent_w * k) * a.n_pos + b : -1;   // this negative's record(s)
+            bool wrote = false;
             if (!nc.fast) {
                 float hinge;
                 if (standalone_negative<MODEL, L, C>(tm, a, nrow_h, nrow_t, nr, p, hinge)) { cnt++; lsum += hinge; }
+                if (REC && tm.lane == 0) {
+#pragma unroll
+                    for (int w = 0; w < RS::ent_w; w++) a.fdst[m_neg + w * a.n_pos] = -1;
+                }
                 continue;
             }
             float sg[C];
@@ -259,7 +304,8 @@ __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
                     float G[C];
 #pragma unroll
                     for (int c = 0; c < C; c++) { G[c] = -a.unit * sg[c]; At[c] += sg[c]; Ar[c] -= sg[c]; }
-                    side_backward<MODEL, L, C>(tm, a, nrow_h, sx, G, cx.cw, acw);
+                    side_backward<MODEL, L, C, REC>(tm, a, nrow_h, sx, G, cx.cw, acw, m_neg);
+                    wrote = true;
                 }
             } else if (!nc.same_t) {  // tail corrupted (corrupt_head keeps h, Base.cpp:119-121)
                 Side<C> sx;
@@ -271,7 +317,8 @@ __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
                     float G[C];
 #pragma unroll
                     for (int c = 0; c < C; c++) { G[c] = a.unit * sg[c]; Ah[c] -= sg[c]; Ar[c] -= sg[c]; }
-                    side_backward<MODEL, L, C>(tm, a, nrow_t, sx, G, cx.cw, acw);
+                    side_backward<MODEL, L, C, REC>(tm, a, nrow_t, sx, G, cx.cw, acw, m_neg);
+                    wrote = true;
                 }
             } else {  // relation vector corrupted while both projected entities are shared (TransE; TransR with negative_rel == 0)
                 float raw[C], xn[C], inv; bool uc;
@@ -285,9 +332,18 @@ __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
 #pragma unroll
                     for (int c = 0; c < C; c++) { G[c] = -a.unit * sg[c]; Ah[c] -= sg[c]; At[c] += sg[c]; }
                     tm.normalize_bwd(xn, G, inv, uc, g);
-                    tm.add(a.g_rel, nr, g);
+                    put_row<REC>(tm, a, a.g_rel, nr, hub + nr, m_neg, g);
+                    wrote = true;
                 }
             }
+            if (REC && !wrote && tm.lane == 0) {   // hinge inactive: no record in this negative's slot(s)
+#pragma unroll
+                for (int w = 0; w < RS::ent_w; w++) a.fdst[m_neg + w * a.n_pos] = -1;
+            }
+        }
+        if (REC && cnt == 0 && tm.lane == 0) {
+#pragma unroll
+            for (int sl = 0; sl < RS::group; sl++) a.fdst[sl * a.n_pos + b] = -1;
         }
         if (cnt > 0) {
             const float fc = (float)cnt;
@@ -298,9 +354,9 @@ __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
                 Gt[c] = a.unit * (At[c] - fc * sp[c]);
                 Gr[c] = a.unit * (Ar[c] + fc * sp[c]);
             }
-            side_backward<MODEL, L, C>(tm, a, row_h, sh, Gh, cx.cw, acw);
-            side_backward<MODEL, L, C>(tm, a, row_t, st, Gt, cx.cw, acw);
-            ctx_backward<MODEL, L, C>(tm, a, r, cx, Gr, acw);
+            side_backward<MODEL, L, C, REC>(tm, a, row_h, sh, Gh, cx.cw, acw, REC ? RS::h * a.n_pos + b : -1);
+            side_backward<MODEL, L, C, REC>(tm, a, row_t, st, Gt, cx.cw, acw, REC ? RS::t * a.n_pos + b : -1);
+            ctx_backward<MODEL, L, C, REC>(tm, a, r, cx, Gr, acw, REC ? RS::r * a.n_pos + b : -1, hub);
         }
     }
     if (tm.lane == 0) red[team_in_block] = lsum;
@@ -906,6 +962,30 @@ static void launch_fb(const FbArgs &a, float *d_loss, hipStream_t stream) {
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, a.loss_partials, (int)blocks, a.unit, d_loss);
 }
 
+template <int MODEL, int L, int C>
+static void launch_fb_records(const FbArgs &a, float *d_loss, hipStream_t stream) {
+    constexpr int TEAMS = 256 / L;
+    long long blocks = (a.n_pos + TEAMS - 1) / TEAMS;
+    if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((fwdbwd_kernel<MODEL, L, C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, a.loss_partials, (int)blocks, a.unit, d_loss);
+}
+
+template <int MODEL>
+static int dispatch_fb_records(const FbArgs &a, float *d_loss, hipStream_t stream) {
+    const int D = a.D;
+    if (D <= 16) launch_fb_records<MODEL, 16, 1>(a, d_loss, stream);
+    else if (D <= 32) launch_fb_records<MODEL, 16, 2>(a, d_loss, stream);
+    else if (D <= 64) launch_fb_records<MODEL, 16, 4>(a, d_loss, stream);
+    else if (D <= 128) launch_fb_records<MODEL, 32, 4>(a, d_loss, stream);
+    else if (D <= 256) launch_fb_records<MODEL, 64, 4>(a, d_loss, stream);
+    else if (D <= 512) launch_fb_records<MODEL, 64, 8>(a, d_loss, stream);
+    else if (D <= 1024) launch_fb_records<MODEL, 64, 16>(a, d_loss, stream);
+    else return fail(KGE_ERR_UNSUPPORTED, "embedding dimension > 1024 is not supported by the vector-model kernels");
+    return KGE_OK;
+}
+
 template <int MODEL>
 static int dispatch_fb(const FbArgs &a, float *d_loss, hipStream_t stream) {
     const int D = a.D;
@@ -964,6 +1044,39 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
     a.loss_partials = e.dev.loss_partials;
     a.P = nullptr; a.GP = nullptr; a.negative_rel = m.negative_rel;
     int rc;
+    // Float-record path: gradient rows are stored as records, ordered by destination row and summed by
+    // segments into the accumulators (plain stores + one sorted pass instead of memory-side fp32 atomics,
+    // which cap at ~1.1 TB/s).  Worth it once a step has enough rows to fill the chip.
+    const int64_t slots = m.model == KGE_TRANSE ? 3 + n_neg : (m.model == KGE_TRANSH ? 4 + n_neg : 6 + 2 * n_neg);
+    const int64_t M = n_pos * slots;
+    // relation-side rows: every group writes 1 (TransE) or 2 of them, i.e. a share 2/slots of all records lands on
+    // R or 2R rows.  Give them the same share of the (virtual) row space so the sort buckets stay balanced.
+    const int64_t ent_rows = (m.model == KGE_TRANSD ? 2 : 1) * m.ent_total;
+    const int64_t hub_rows = (m.model == KGE_TRANSE ? 1 : 2) * m.rel_total;
+    const int64_t group_rel = m.model == KGE_TRANSE ? 1 : 2;
+    int64_t hub_k = hub_rows > 0 ? (group_rel * ent_rows) / ((slots - group_rel) * hub_rows) : 1;
+    if (hub_k < 1) hub_k = 1;
+    if (hub_k > 4096) hub_k = 4096;
+    const int64_t rows = ent_rows + hub_k * hub_rows;
+    if (e.float_records && M >= e.float_records_min && M < (int64_t(1) << 31) && rows < (int64_t(1) << 31) - 1 && a.D <= 1024) {
+        float *frec = nullptr;
+        int32_t *fdst = nullptr;
+        if ((rc = float_records_workspace(M, a.D, frec, fdst))) return rc;
+        a.frec = frec; a.fdst = fdst;
+        a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total;
+        a.hub_base = ent_rows; a.hub_k = (int)hub_k; a.hub_rows = (int)hub_rows;
+        switch (m.model) {
+            case KGE_TRANSE: rc = dispatch_fb_records<KGE_TRANSE>(a, d_loss, stream); break;
+            case KGE_TRANSH: rc = dispatch_fb_records<KGE_TRANSH>(a, d_loss, stream); break;
+            case KGE_TRANSD: rc = dispatch_fb_records<KGE_TRANSD>(a, d_loss, stream); break;
+            default: return fail(KGE_ERR_BAD_ARG, "unknown model id");
+        }
+        if (rc) return rc;
+        FloatRowSpace rs;
+        rs.g_ent = grads[0]; rs.g_rel = grads[1]; rs.g_auxr = grads[2]; rs.g_auxe = grads[3];
+        rs.E = m.ent_total; rs.R = m.rel_total; rs.hub_base = ent_rows; rs.hub_rows = hub_rows; rs.rows = rows;
+        return float_records_reduce(M, a.D, rs, stream);
+    }
     switch (m.model) {
         case KGE_TRANSE: rc = dispatch_fb<KGE_TRANSE>(a, d_loss, stream); break;
         case KGE_TRANSH: rc = dispatch_fb<KGE_TRANSH>(a, d_loss, stream); break;

@@ -36,6 +36,8 @@ int transe_deferred_groups(int32_t *out);
 
 namespace {
 
+int bits_for_rows(int64_t v) { int b = 1; while ((int64_t(1) << b) <= v) b++; return b; }
+
 struct CtWork {
     uint32_t *rec = nullptr;
     int32_t *dst = nullptr, *dst_sorted = nullptr, *ids = nullptr, *ids_sorted = nullptr;
@@ -336,6 +338,139 @@ __device__ __forceinline__ float count_grad(float unit, float inv, float s, floa
     return __fmul_rn(__fmul_rn(unit, inv), __fsub_rn(s, __fmul_rn(d, xn)));
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Float records (TransH / TransD / TransE without counts): the same ordering machinery, fp32 payload.
+// fwdbwd_kernel<..., REC> stores each gradient row as a D-float record; here the records are ordered by
+// destination row and summed by segments INTO the dense accumulators (which may already hold the few
+// rows the atomic standalone path added): interior runs of a chunk are read-modify-written by their one
+// owner, the first and last run of a chunk use atomics.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float *float_row_ptr(const FloatRowSpace &rs, long long row, int D) {
+    if (row < rs.E) return rs.g_ent + row * D;
+    if (row < rs.hub_base) return rs.g_auxe + (row - rs.E) * D;
+    const long long q = (row - rs.hub_base) % rs.hub_rows;   // fold the hub copies back
+    return q < rs.R ? rs.g_rel + q * D : rs.g_auxr + (q - rs.R) * D;
+}
+
+template <int L, int C>
+__device__ __forceinline__ void flush_run_f32(const FloatRowSpace &rs, int D, int lane, long long row, const float (&acc)[C], bool atomic) {
+    float *p = float_row_ptr(rs, row, D);
+    atomic = atomic || row >= rs.hub_base;   // several virtual hub rows fold onto one real row: never exclusive
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int e = lane + L * c;
+        if (e < D) {
+            if (atomic) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(p + e), acc[c]);
+            else p[e] += acc[c];
+        }
+    }
+}
+
+template <int L, int C>
+__global__ __launch_bounds__(256) void segsum_f32_kernel(const float *__restrict__ rec, const int32_t *__restrict__ keys,
+                                                         const int32_t *__restrict__ ids, const int32_t *__restrict__ n_valid_p,
+                                                         FloatRowSpace rs, int D, int chunk_len) {
+    constexpr int TEAMS = 256 / L;
+    constexpr int U = 4;
+    const int lane = threadIdx.x % L;
+    const int n_valid = n_valid_p[0];
+    const long long chunk = (long long)blockIdx.x * TEAMS + threadIdx.x / L;
+    const long long start = chunk * chunk_len;
+    if (start >= n_valid) return;
+    const int n = (int)min((long long)chunk_len, n_valid - start);
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) acc[c] = 0.f;
+    int cur = keys[start];
+    bool first_run = true;
+    for (int i0 = 0; i0 < n; i0 += U) {
+        int k[U];
+        float x[U][C];
+#pragma unroll
+        for (int u = 0; u < U; u++) {   // unconditional (clamped) loads: all in flight together
+            const int i = min(i0 + u, n - 1);
+            k[u] = keys[start + i];
+            const float *p = rec + (long long)ids[start + i] * D;
+#pragma unroll
+            for (int c = 0; c < C; c++) { const int e = lane + L * c; x[u][c] = p[e < D ? e : 0]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (i0 + u >= n) break;
+            if (k[u] != cur) {
+                flush_run_f32<L, C>(rs, D, lane, cur, acc, first_run);
+#pragma unroll
+                for (int c = 0; c < C; c++) acc[c] = 0.f;
+                cur = k[u];
+                first_run = false;
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++) acc[c] += x[u][c];
+        }
+    }
+    flush_run_f32<L, C>(rs, D, lane, cur, acc, true);
+}
+
+}  // namespace
+
+int float_records_workspace(int64_t M, int D, float *&rec, int32_t *&dst) {
+    int rc = ensure_counts_work(M, (size_t)D);
+    if (rc) return rc;
+    rec = reinterpret_cast<float *>(g_c.rec);
+    dst = g_c.dst;
+    return KGE_OK;
+}
+
+int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t stream) {
+    int rc;
+    const int rows = (int)rs.rows;
+    const int32_t *n_valid_p = nullptr;
+    const int rpb = (rows + NB - 1) / NB;
+    if (rpb <= 8192 && !engine().counts_force_sort) {
+        const int n_tiles = (int)((M + BTILE - 1) / BTILE);
+        if (!g_c.bucket_start) {
+            if ((rc = regrow(g_c.bucket_start, NB + 2, "counts bucket_start"))) return rc;
+            if ((rc = regrow(g_c.tile_hist, 2 * (NB + 2), "counts bucket totals/cursors"))) return rc;
+            if ((rc = hip_check(hipMemset(g_c.tile_hist, 0, sizeof(int32_t) * 2 * (NB + 2)), "zero bucket totals"))) return rc;
+        }
+        int32_t *totals = g_c.tile_hist, *cursor = g_c.tile_hist + (NB + 2);
+        int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
+        hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals);
+        hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(1024), 0, stream, totals, g_c.bucket_start, cursor);
+        hipLaunchKernelGGL(bkt_scatter_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, cursor, pairs);
+        hipLaunchKernelGGL(bkt_sort_kernel, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
+                           g_c.dst_sorted, g_c.ids_sorted);
+        n_valid_p = g_c.bucket_start + NB;
+    } else {
+        int blocks = (int)((M + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(fix_keys_kernel, dim3(blocks), dim3(256), 0, stream, g_c.dst, (long long)M, rows);
+        size_t tmp = g_c.sort_tmp_bytes;
+        rc = hip_check(rocprim::radix_sort_pairs(g_c.sort_tmp, tmp, g_c.dst, g_c.dst_sorted, g_c.ids, g_c.ids_sorted, (size_t)M, 0,
+                                                 bits_for_rows(rows), stream), "float records sort");
+        if (rc) return rc;
+        hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(64), 0, stream, g_c.dst_sorted, (int)M, rows, g_c.n_valid);
+        n_valid_p = g_c.n_valid;
+    }
+    const float *rec = reinterpret_cast<const float *>(g_c.rec);
+    // shorter chunks while the step is small: the per-team record loop is a chain of dependent loads
+    const int chunk_len = M >= (int64_t(1) << 20) ? 64 : (M >= (int64_t(1) << 18) ? 32 : 16);
+#define KGE_SEGF(LL, CC)                                                                                              \
+    {                                                                                                                 \
+        const long long chunks = (M + chunk_len - 1) / chunk_len;                                                     \
+        const long long nb = (chunks + (256 / LL) - 1) / (256 / LL);                                                  \
+        hipLaunchKernelGGL((segsum_f32_kernel<LL, CC>), dim3((unsigned)nb), dim3(256), 0, stream, rec, g_c.dst_sorted, \
+                           g_c.ids_sorted, n_valid_p, rs, D, chunk_len);                                              \
+    }
+    if (D <= 16) KGE_SEGF(16, 1) else if (D <= 32) KGE_SEGF(16, 2) else if (D <= 64) KGE_SEGF(16, 4)
+    else if (D <= 128) KGE_SEGF(32, 4) else if (D <= 256) KGE_SEGF(64, 4) else if (D <= 512) KGE_SEGF(64, 8) else KGE_SEGF(64, 16)
+#undef KGE_SEGF
+    return hip_check(hipGetLastError(), "float records reduce launch");
+}
+
+namespace {
+
 // stage 3.  optimizer: 0 = SGD (lr), 1 = Adam (lr = lr_t)
 struct ApplyArgs {
     float *p, *m, *v;
@@ -422,7 +557,6 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
     else if (D <= 256) { CALL(64, 4); } else if (D <= 512) { CALL(64, 8); } \
     else { CALL(64, 16); }
 
-int bits_for_rows(int64_t v) { int b = 1; while ((int64_t(1) << b) <= v) b++; return b; }
 
 }  // namespace
 

@@ -37,7 +37,8 @@ def test_grow_table_appends_xavier_or_zero_rows():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("opt", ["SGD", "Adam"])
-def test_checkpoint_resume_is_bit_identical(tmp_path, opt):
+def test_checkpoint_resume_is_bit_identical(tmp_path, opt, monkeypatch):
+    monkeypatch.setenv("KGE_COUNTS_MIN_RECORDS", "0")   # the exact count pipeline: reproducible bit for bit at any step size
     out = str(tmp_path / "run")
     base = ["--input_path", os.path.join(GOLDEN, "kg_small"), "--output_path", out, "--embedding_dimension", "32",
             "--n_mini_batches", "5", "--ent_neg_rate", "3", "--alpha", "0.01", "--optimizer", opt, "--bern_flag", "1"]

@@ -26,6 +26,7 @@ def _worker(rank, world, port, out_dir, model_name, opt, sparse=False):
     con.set_work_threads(8); con.set_bern(1); con.set_dimension(48); con.set_nbatches(10)  # B = 600
     con.set_ent_neg_rate(3); con.set_alpha(0.02); con.set_opt_method(opt)
     con.sparse_rows = sparse
+    con.counts_min_records = 0
     con.init()
     con.set_model_and_session(getattr(pkg, model_name))
     assert con.sparse_rows == sparse

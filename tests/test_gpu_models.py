@@ -69,6 +69,7 @@ def make_engine(model, E, R, D, n, nr, margin=1.0, opt="SGD", alpha=0.01, params
     import openkeonspark_amd as pkg
     con = Config()
     con.use_counts = use_counts
+    con.counts_min_records = 0   # small test batches must still exercise the count pipeline
     con.set_ent_neg_rate(n); con.set_rel_neg_rate(nr); con.set_margin(margin)
     con.set_opt_method(opt); con.set_alpha(alpha)
     if Dr is None:
@@ -115,9 +116,24 @@ def test_transr_forward_backward_matches_oracle(E, R, De, Dr, n, nr, foreign):
         assert relerr(g_g[k], g_o[k]) < RTOL, (k, relerr(g_g[k], g_o[k]))
 
 
+@pytest.fixture(params=["atomic", "records-bucket", "records-sort"])
+def grad_path(request):
+    """The three accumulations of the fp32 gradient rows: memory-side atomics, or float records ordered by the
+    two-level counting sort / by rocPRIM's radix sort and summed by segments (the default on large steps)."""
+    from openkeonspark_amd import _lib
+    L = _lib.lib()
+    L.kge_set_option(b"float_records", 0 if request.param == "atomic" else 1)
+    L.kge_set_option(b"float_records_min", 0)
+    L.kge_set_option(b"counts_force_sort", 1 if request.param == "records-sort" else 0)
+    yield request.param
+    L.kge_set_option(b"float_records", 1)
+    L.kge_set_option(b"float_records_min", 1 << 16)
+    L.kge_set_option(b"counts_force_sort", 0)
+
+
 @pytest.mark.parametrize("model,E,R,D", CASES)
 @pytest.mark.parametrize("n,nr,foreign", [(1, 0, 0.0), (5, 0, 0.0), (2, 1, 0.0), (3, 1, 0.3)])
-def test_forward_backward_matches_oracle(model, E, R, D, n, nr, foreign):
+def test_forward_backward_matches_oracle(model, E, R, D, n, nr, foreign, grad_path):
     import torch
     rng = np.random.default_rng(seed_of(model, D, n, nr))
     B = 257
@@ -140,7 +156,7 @@ def test_forward_backward_matches_oracle(model, E, R, D, n, nr, foreign):
 
 @pytest.mark.parametrize("model", ["transe", "transh", "transd", "transr"])
 @pytest.mark.parametrize("opt", ["SGD", "Adam"])
-def test_training_steps_match_oracle(model, opt):
+def test_training_steps_match_oracle(model, opt, grad_path):
     """Several optimiser steps on fed batches: parameters, Adam slots and losses track the oracle."""
     rng = np.random.default_rng(11)
     E, R, D, B, n = 120, 6, 64, 128, 3
@@ -368,6 +384,7 @@ def test_prefetched_sampling_is_bit_identical(fb_dir):
     for prefetch in (False, True):
         con = Config()
         con.prefetch_sampling = prefetch
+        con.counts_min_records = 0   # exact count pipeline: reproducible bit for bit
         con.set_in_path(fb_dir); con.set_work_threads(8); con.set_bern(1); con.set_dimension(64); con.set_nbatches(100)
         con.set_ent_neg_rate(4); con.set_alpha(0.01); con.set_opt_method("Adam")
         con.init()

@@ -26,6 +26,7 @@ def make_config(kg, dim, n_neg, sparse, nbatches=4, threads=4, seed=7):
     con.set_rel_neg_rate(0)
     con.set_opt_method("SGD")
     con.sparse_rows = sparse
+    con.counts_min_records = 0
     con.init()
     torch.manual_seed(seed)
     con.set_model_and_session(ok.TransE)
