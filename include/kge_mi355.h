@@ -115,6 +115,8 @@ const char *kge_version(void);
  *   "float_records":     1 (default) = kge_forward_backward stores TransE/H/D gradient rows as records and sums
  *                        them by destination after a sort; 0 = fp32 atomic adds straight into the accumulators
  *   "float_records_min": smallest number of gradient rows per step that takes the record path (default 65536: measured cross-over, tools/sweep_paths.py)
+ *   "index_device_min":  training sets with at least this many lines are indexed on the device (rocPRIM sorts,
+ *                        same arrays bit for bit); default 4194304, 0 = always, negative = never
  *   "time_emit":         1 = bracket the TransE emit kernel with HIP events on its launch stream
  *   "libc_rand_restart": restart the glibc-compatible seed generator, as in a fresh process (the next
  *                        randReset then yields 1804289383, 846930886, ... again) */

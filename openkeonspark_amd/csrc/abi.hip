@@ -101,6 +101,24 @@ static void adopt_index(KgIndex &&ix) {
     e.dev.uploaded = false;
 }
 
+// Reader.h:102-177 on the host (kg_index.cpp) or, for large training sets, on the device (index_build.hip);
+// both produce the same arrays bit for bit
+static std::string build_and_adopt(int64_t E, int64_t R, int64_t nb, int64_t n, const int64_t *h, const int64_t *t, const int64_t *r) {
+    Engine &e = engine();
+    if (e.index_device_min >= 0 && n >= e.index_device_min && device_ok() && device_index_build_supported(E, R, n)) {
+        KgIndex ix;
+        std::string err = build_index_device(ix, e.dev, E, R, nb, n, h, t, r);
+        if (!err.empty()) { e.dev.uploaded = false; return err; }
+        e.index = std::move(ix);   // e.dev already holds the arrays (uploaded = true)
+        return "";
+    }
+    KgIndex ix;
+    std::string err = build_index(ix, E, R, nb, n, h, t, r);
+    if (!err.empty()) return err;
+    adopt_index(std::move(ix));
+    return "";
+}
+
 }  // namespace kge
 
 using namespace kge;
@@ -143,10 +161,8 @@ void importTrainFiles(void) {
     std::printf("The total of entities is %ld.\n", (long)E);
     if (nb > 0) std::printf("The total number of new batch triples is: %ld\n", (long)nb);
     std::printf("The total of train triples is %ld.\n", (long)h.size());
-    KgIndex ix;
-    err = build_index(ix, E, R, nb, (int64_t)h.size(), h.data(), t.data(), r.data());
+    err = build_and_adopt(E, R, nb, (int64_t)h.size(), h.data(), t.data(), r.data());
     if (!err.empty()) { set_error(err); return; }
-    adopt_index(std::move(ix));
     std::fflush(stdout);
 }
 
@@ -204,6 +220,7 @@ int kge_set_option(const char *name, INT value) {
     if (n == "inv_table_max_bytes") { engine().inv_table_max_bytes = value; return KGE_OK; }
     if (n == "float_records") { engine().float_records = value != 0; return KGE_OK; }
     if (n == "float_records_min") { engine().float_records_min = value; return KGE_OK; }
+    if (n == "index_device_min") { engine().index_device_min = value; return KGE_OK; }
     if (n == "time_emit") { engine().time_emit = value != 0; return KGE_OK; }
     if (n == "libc_rand_restart") { engine().libc = LibcRand(); return KGE_OK; }  // as in a fresh process
     return fail(KGE_ERR_BAD_ARG, "kge_set_option: unknown option " + n);
@@ -220,11 +237,9 @@ int kge_last_kernel_ms(const char *name, float *ms) {
 
 int kge_import_train_arrays(INT ent_total, INT rel_total, INT n, const INT *h, const INT *t, const INT *r,
                             INT new_batch_total) {
-    KgIndex ix;
-    std::string err = build_index(ix, ent_total, rel_total, new_batch_total, n, (const int64_t *)h, (const int64_t *)t,
-                                  (const int64_t *)r);
+    std::string err = build_and_adopt(ent_total, rel_total, new_batch_total, n, (const int64_t *)h, (const int64_t *)t,
+                                      (const int64_t *)r);
     if (!err.empty()) return fail(KGE_ERR_BAD_ARG, err);
-    adopt_index(std::move(ix));
     return KGE_OK;
 }
 

@@ -52,6 +52,7 @@ struct Engine {
     int64_t inv_table_max_bytes = int64_t(256) << 20;  // TransE emit: per-row inverse-norm table only while the tables are this small
     int float_records = 1;              // TransH / TransD (and TransE without counts): record + segmented-sum path instead of fp32 atomics
     int64_t float_records_min = 1 << 16; // ... from this many gradient rows per step (below it the atomic kernel alone is quicker)
+    int64_t index_device_min = int64_t(1) << 22;  // training sets from this many lines on are indexed on the device (index_build.hip); < 0 = never
     int counts_force_sort = 0;  // test hook: take the sort+segsum reduction even for small tables
 };
 
@@ -93,6 +94,11 @@ struct FloatRowSpace {   // virtual row space of models.hip's FbArgs::frec recor
 };
 int float_records_workspace(int64_t M, int D, float *&rec, int32_t *&dst);
 int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t stream);
+
+// device-side index build (index_build.hip)
+bool device_index_build_supported(int64_t E, int64_t R, int64_t n);
+std::string build_index_device(KgIndex &ix, DeviceIndex &dev, int64_t E, int64_t R, int64_t new_batch, int64_t n, const int64_t *h,
+                               const int64_t *t, const int64_t *r);
 
 // ---- launchers implemented in the .hip files ------------------------------------------------
 int launch_sampler(int32_t *d_h, int32_t *d_t, int32_t *d_r, int64_t B, int64_t neg, int64_t negrel, int64_t thread_lo,

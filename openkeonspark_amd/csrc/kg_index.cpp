@@ -179,6 +179,14 @@ std::string build_index(KgIndex &ix, int64_t E, int64_t R, int64_t new_batch, in
         ix.grp[i] = Int4{hr_off[u], hr_len[u], tr_off[u], tr_len[u]};
         ix.ht[i] = Int2{ht_off[u], ht_len[u]};
     }
+    relation_means(ix, freq_rel, groups_hr, groups_tr);
+    ix.loaded = true;
+    return "";
+}
+
+void relation_means(KgIndex &ix, const std::vector<int64_t> &freq_rel, const std::vector<int64_t> &groups_hr,
+                    const std::vector<int64_t> &groups_tr) {
+    const int64_t R = ix.rel_total;
     // Reader.h:160-177.  The reference counts groups by adding 1.0f to a float, which stops
     // growing at 2^24, and divides a long by that float.  Reproduce both effects.
     ix.left_mean.resize(R); ix.right_mean.resize(R); ix.bern_prob.resize(R);
@@ -194,8 +202,6 @@ std::string build_index(KgIndex &ix, int64_t E, int64_t R, int64_t new_batch, in
         volatile float den = rm + lm;
         ix.bern_prob[q] = num / den;
     }
-    ix.loaded = true;
-    return "";
 }
 
 LibcRand::LibcRand() {

@@ -43,6 +43,10 @@ bool read_all_longs(const std::string &path, std::vector<int64_t> &out);
 std::string build_index(KgIndex &ix, int64_t ent_total, int64_t rel_total, int64_t new_batch, int64_t n,
                         const int64_t *h, const int64_t *t, const int64_t *r);
 
+// Reader.h:160-177 + Base.cpp:117 from the three per-relation integer counts (shared by the host and device builds)
+void relation_means(KgIndex &ix, const std::vector<int64_t> &freq_rel, const std::vector<int64_t> &groups_hr,
+                    const std::vector<int64_t> &groups_tr);
+
 // glibc rand() with the default seed, continuing across calls (Random.h:9-13 never calls srand).
 class LibcRand {
    public:

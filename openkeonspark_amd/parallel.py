@@ -44,6 +44,18 @@ def allreduce_gradients(tensors, group=None):
     """SUM all-reduce of the per-table gradient accumulators (and the loss scalar).  Launched
     asynchronously so the tables overlap on the wire; returns when all are complete."""
     import torch.distributed as dist
+    import os
+    if len(tensors) > 1 and tensors[0].is_cuda and dist.get_backend(group) == "nccl" and os.environ.get("KGE_NO_COALESCE") != "1":
+        # one RCCL group call: the tables and the loss scalar travel in a single fused launch instead of one
+        # latency-bound collective each
+        try:
+            with dist._coalescing_manager(group=group, device=tensors[0].device, async_ops=True) as cm:
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            cm.wait()
+            return
+        except (AttributeError, TypeError, RuntimeError):
+            pass
     works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in tensors]
     for w in works:
         w.wait()
