@@ -198,6 +198,13 @@ int kge_sgd_update(float *d_p, float *d_g, int64_t n, float lr, void *stream);
 int kge_adam_update(float *d_p, float *d_m, float *d_v, float *d_g, int64_t n, float lr_t, float beta1,
                     float beta2, float eps, void *stream);
 
+/* The same two updates for all tables of a model in ONE launch (n_tables <= KGE_MAX_TABLES; numel[i] elements each) */
+int kge_sgd_update_tables(int32_t n_tables, float *const d_p[KGE_MAX_TABLES], float *const d_g[KGE_MAX_TABLES],
+                          const INT numel[KGE_MAX_TABLES], float lr, void *stream);
+int kge_adam_update_tables(int32_t n_tables, float *const d_p[KGE_MAX_TABLES], float *const d_m[KGE_MAX_TABLES],
+                           float *const d_v[KGE_MAX_TABLES], float *const d_g[KGE_MAX_TABLES], const INT numel[KGE_MAX_TABLES],
+                           float lr_t, float beta1, float beta2, float eps, void *stream);
+
 /* ---- TransE sign-count path (exact integer gradients, no fp32 atomics) ----------------------
  * For the L1 score of TransE.py:11-15 the gradient w.r.t. every l2-normalised vector is (1/denom) x an
  * integer vector of signs, so the backward can be carried as exact int32 COUNTS per table row:
@@ -207,7 +214,9 @@ int kge_adam_update(float *d_p, float *d_m, float *d_v, float *d_g, int64_t n, f
  * counts are order-independent, so a data-parallel all-reduce of them is exact and every replica
  * stays bit-identical.  Negatives that are not sampler-shaped (more than one slot differs from the
  * positive) are differentiated exactly in fp32 into the residual accumulators d_resid_ent [E,D] /
- * d_resid_rel [R,D] (zero on entry, all-zero afterwards for sampler batches).
+ * d_resid_rel [R,D] (zero on entry, all-zero afterwards for sampler batches).  d_resid_ent = d_resid_rel = NULL
+ * is the caller's guarantee that the batch IS sampler-shaped (it came from kge_sampling_device): no deferral
+ * bookkeeping, no fp32 pass, and the loss is written by the emit kernel itself.
  * kge_transe_apply_counts: per row g = (1/denom)*inv*(S - x^<x^,S>) + resid (the normalise-backward
  * applied once to the summed counts), then SGD (adam=0, lr) or TF1 Adam (adam=1, lr = lr_t) in place. */
 int kge_transe_counts_supported(const kge_model_desc *m, INT n_neg);
@@ -216,6 +225,10 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
                               int32_t *d_counts, float *d_resid_ent, float *d_resid_rel, float *d_loss, void *stream);
 int kge_transe_apply_counts(float *d_p, float *d_m, float *d_v, int32_t *d_counts, float *d_resid, int64_t rows, int32_t dim,
                             INT denom, int32_t adam, float lr, float beta1, float beta2, float eps, void *stream);
+/* both tables ([0] = ent_embeddings, [1] = rel_embeddings; d_counts = the whole [(E+R), D] image) in one launch */
+int kge_transe_apply_counts_tables(const kge_model_desc *m, float *const d_p[2], float *const d_m[2], float *const d_v[2],
+                                   int32_t *d_counts, float *const d_resid[2], INT denom, int32_t adam, float lr, float beta1,
+                                   float beta2, float eps, void *stream);
 
 /* ---- TransE sign-count path, stage level: for tables too large for a dense count image and for the
  * multi-GPU exchange, where the int8 records (8x smaller than fp32 gradient rows) are the wire format ----

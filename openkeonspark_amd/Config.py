@@ -277,6 +277,10 @@ class Config(object):
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._tab_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._tables])
         self._grad_ptrs = _lib.table_ptrs([g.data_ptr() for g in self._grads])
+        self._numel = (ctypes.c_int64 * _lib.KGE_MAX_TABLES)(*[t.numel() for t in self._tables])
+        if self._adam:
+            self._adam_m_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._adam_m])
+            self._adam_v_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._adam_v])
         self._dev_batch = None
         self._side_stream = None
         self._prefetched = None
@@ -376,16 +380,14 @@ class Config(object):
         if self._adam:
             f = np.float32
             lr_t = f(f(self.alpha) * np.sqrt(f(1) - self._beta2_power, dtype=np.float32) / (f(1) - self._beta1_power))
-            for p, m, v, g in zip(self._tables, self._adam_m, self._adam_v, self._grads):
-                _lib.check(self.lib.kge_adam_update(p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), p.numel(),
-                                                    float(lr_t), self.adam_beta1, self.adam_beta2, self.adam_epsilon,
-                                                    st), self.lib)
+            _lib.check(self.lib.kge_adam_update_tables(len(self._tables), self._tab_ptrs, self._adam_m_ptrs, self._adam_v_ptrs,
+                                                       self._grad_ptrs, self._numel, float(lr_t), self.adam_beta1,
+                                                       self.adam_beta2, self.adam_epsilon, st), self.lib)
             self._beta1_power = f(self._beta1_power * f(self.adam_beta1))
             self._beta2_power = f(self._beta2_power * f(self.adam_beta2))
         else:
-            for p, g in zip(self._tables, self._grads):
-                _lib.check(self.lib.kge_sgd_update(p.data_ptr(), g.data_ptr(), p.numel(), float(self.alpha), st),
-                           self.lib)
+            _lib.check(self.lib.kge_sgd_update_tables(len(self._tables), self._tab_ptrs, self._grad_ptrs, self._numel,
+                                                      float(self.alpha), st), self.lib)
         self.global_step += 1
 
     def train_step(self, batch_h=None, batch_t=None, batch_r=None, batch_y=None, sync=True):
@@ -416,7 +418,7 @@ class Config(object):
             if batch_h is None and self.prefetch_sampling:
                 self._prefetch_next_batch()
         elif self.use_counts and big:
-            self.forward_counts(dev, n_pos, stride, denom)
+            self.forward_counts(dev, n_pos, stride, denom, sampler_shaped=batch_h is None)
             if batch_h is None and self.prefetch_sampling:
                 self._prefetch_next_batch()
             if self.world_size > 1:
@@ -495,30 +497,29 @@ class Config(object):
         n = int(self._sparse_buf["n_rows"].item())
         return self._sparse_buf["rows"][:n], self._sparse_buf["row_counts"][:n]
 
-    def forward_counts(self, dev_batch, n_pos, stride, denom):
-        """TransE sign-count forward/backward: exact int32 gradient counts -> self._counts."""
+    def forward_counts(self, dev_batch, n_pos, stride, denom, sampler_shaped=False):
+        """TransE sign-count forward/backward: exact int32 gradient counts -> self._counts.
+        sampler_shaped=True (a device-sampled batch): no residual pass is needed (include/kge_mi355.h)."""
+        resid = (None, None) if sampler_shaped else (self._grads[0].data_ptr(), self._grads[1].data_ptr())
         _lib.check(self.lib.kge_transe_forward_counts(
             ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(),
             dev_batch[0].data_ptr(), dev_batch[1].data_ptr(), dev_batch[2].data_ptr(), n_pos,
             self.negative_ent + self.negative_rel, stride, denom, self._counts.data_ptr(),
-            self._grads[0].data_ptr(), self._grads[1].data_ptr(), self._loss.data_ptr(), self._stream()), self.lib)
+            resid[0], resid[1], self._loss.data_ptr(), self._stream()), self.lib)
 
     def apply_counts(self, denom):
-        """Normalise-backward on the summed counts + SGD / TF1 Adam, per table (distribute_training.py:95-101)."""
+        """Normalise-backward on the summed counts + SGD / TF1 Adam, both tables in one launch
+        (distribute_training.py:95-101)."""
         st = self._stream()
         f = np.float32
         if self._adam:
             lr = float(f(f(self.alpha) * np.sqrt(f(1) - self._beta2_power, dtype=np.float32) / (f(1) - self._beta1_power)))
         else:
             lr = float(self.alpha)
-        D = self.hidden_size
-        for i, (row0, rows) in enumerate(((0, self.entTotal), (self.entTotal, self.relTotal))):
-            m = self._adam_m[i].data_ptr() if self._adam else None
-            v = self._adam_v[i].data_ptr() if self._adam else None
-            _lib.check(self.lib.kge_transe_apply_counts(
-                self._tables[i].data_ptr(), m, v, self._counts.data_ptr() + row0 * D * 4, self._grads[i].data_ptr(),
-                rows, D, denom, 1 if self._adam else 0, lr, self.adam_beta1, self.adam_beta2, self.adam_epsilon, st),
-                self.lib)
+        _lib.check(self.lib.kge_transe_apply_counts_tables(
+            ctypes.byref(self._desc), self._tab_ptrs, self._adam_m_ptrs if self._adam else None,
+            self._adam_v_ptrs if self._adam else None, self._counts.data_ptr(), self._grad_ptrs, denom,
+            1 if self._adam else 0, lr, self.adam_beta1, self.adam_beta2, self.adam_epsilon, st), self.lib)
         if self._adam:
             self._beta1_power = f(self._beta1_power * f(self.adam_beta1))
             self._beta2_power = f(self._beta2_power * f(self.adam_beta2))

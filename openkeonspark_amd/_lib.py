@@ -66,11 +66,14 @@ def _declare(L):
     L.kge_forward_backward.argtypes = [ctypes.POINTER(ModelDesc), tabs, vp, vp, vp, i64, i64, i64, i64, tabs, vp, vp]
     L.kge_sgd_update.argtypes = [vp, vp, i64, f32, vp]
     L.kge_adam_update.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp]
+    L.kge_sgd_update_tables.argtypes = [i32, vp, vp, vp, f32, vp]
+    L.kge_adam_update_tables.argtypes = [i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp]
     L.kge_predict.argtypes = [ctypes.POINTER(ModelDesc), tabs, vp, vp, vp, i64, vp, vp]
     L.kge_transe_counts_supported.argtypes = [ctypes.POINTER(ModelDesc), i64]
     L.kge_transe_forward_counts.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp]
     L.kge_transe_apply_counts.argtypes = [vp, vp, vp, vp, vp, i64, i32, i64, i32, f32, f32, f32, f32, vp]
     L.kge_transe_deferred_groups.argtypes = [ctypes.POINTER(ctypes.c_int32)]
+    L.kge_transe_apply_counts_tables.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, vp]
     L.kge_transe_record_dwords.restype = i64
     L.kge_transe_record_dwords.argtypes = [ctypes.POINTER(ModelDesc)]
     L.kge_transe_emit_records.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]

@@ -333,6 +333,17 @@ int kge_adam_update(float *d_p, float *d_m, float *d_v, float *d_g, int64_t n, f
     return launch_adam(d_p, d_m, d_v, d_g, n, lr_t, beta1, beta2, eps, (hipStream_t)stream);
 }
 
+int kge_sgd_update_tables(int32_t n_tables, float *const d_p[KGE_MAX_TABLES], float *const d_g[KGE_MAX_TABLES],
+                          const INT numel[KGE_MAX_TABLES], float lr, void *stream) {
+    return launch_sgd_tables(n_tables, d_p, d_g, (const int64_t *)numel, lr, (hipStream_t)stream);
+}
+
+int kge_adam_update_tables(int32_t n_tables, float *const d_p[KGE_MAX_TABLES], float *const d_m[KGE_MAX_TABLES],
+                           float *const d_v[KGE_MAX_TABLES], float *const d_g[KGE_MAX_TABLES], const INT numel[KGE_MAX_TABLES],
+                           float lr_t, float beta1, float beta2, float eps, void *stream) {
+    return launch_adam_tables(n_tables, d_p, d_m, d_v, d_g, (const int64_t *)numel, lr_t, beta1, beta2, eps, (hipStream_t)stream);
+}
+
 int kge_predict(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES], const int32_t *d_h,
                 const int32_t *d_t, const int32_t *d_r, INT n, float *d_out, void *stream) {
     if (!m || !tables || !d_out) return fail(KGE_ERR_BAD_ARG, "kge_predict: null argument");

@@ -32,6 +32,7 @@ struct DeviceIndex {
     int64_t *stage_i64 = nullptr;    // 3 * cap int64 followed by cap floats
     int64_t stage_cap = 0;
     float *loss_partials = nullptr;  // per-block partial losses
+    unsigned *loss_ticket = nullptr; // blocks-done counter: the last block of a forward/backward kernel adds the partials
 };
 
 struct Engine {
@@ -110,6 +111,9 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
 int launch_predict(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
                    const int32_t *d_r, int64_t n, float *d_out, hipStream_t stream);
 int launch_sgd(float *p, float *g, int64_t n, float lr, hipStream_t stream);
+int launch_sgd_tables(int n_tables, float *const *p, float *const *g, const int64_t *numel, float lr, hipStream_t stream);
+int launch_adam_tables(int n_tables, float *const *p, float *const *m, float *const *v, float *const *g, const int64_t *numel,
+                       float lr_t, float b1, float b2, float eps, hipStream_t stream);
 int launch_adam(float *p, float *m, float *v, float *g, int64_t n, float lr_t, float b1, float b2, float eps,
                 hipStream_t stream);
 

@@ -52,11 +52,60 @@ struct FbArgs {
     //   ent [0,E) | ent_transfer [E,2E) (TransD) | hub_k copies of { rel [R] | normal vectors / rel_transfer [R] }
     // group b writes its relation-side rows into copy b % hub_k, so that the records of a hub relation (WN18RR has
     // 11 relations) spread over many sort buckets; the segmented sum folds the copies back onto the real row
+    float *loss_out;        // see finish_loss
+    unsigned *loss_ticket;
     float *frec;
     int32_t *fdst;
     long long hub_base;   // first row of copy 0
     int hub_k, hub_rows;  // copies, rows per copy (R or 2R)
 };
+
+int ensure_loss_buffers();
+
+// Per-block partial hinge sums -> loss = sum / denom (TransE.py:51).  With a.loss_out set, the LAST block to
+// finish (ticket counter) adds the partials in the fixed order loss_finalize_kernel uses and writes the loss,
+// so no separate launch is needed; otherwise the partials are left for loss_finalize_kernel.
+template <int TEAMS>
+__device__ __forceinline__ void finish_loss(const FbArgs &a, float *red, float lsum, int lane, int team_in_block) {
+    __shared__ float sh[256];
+    __shared__ int is_last;
+    if (lane == 0) red[team_in_block] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < TEAMS; i++) s += red[i];
+        is_last = 0;
+        if (a.loss_out) {
+            // No fences: an agent-scope release fence writes back the whole XCD L2 on gfx950 (measured: the emit
+            // kernel went from 119 to 237 us).  Memory-side atomics are coherent across XCDs by themselves: publish
+            // the partial with a RETURNING exchange, wait for it, then take a ticket.
+            unsigned *slot = reinterpret_cast<unsigned *>(a.loss_partials) + blockIdx.x;
+            (void)__hip_atomic_exchange(slot, __float_as_uint(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the exchange has been performed
+            is_last = __hip_atomic_fetch_add(a.loss_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+        } else {
+            a.loss_partials[blockIdx.x] = s;
+        }
+    }
+    if (!a.loss_out) return;
+    __syncthreads();
+    if (!is_last) return;
+    const unsigned *part = reinterpret_cast<const unsigned *>(a.loss_partials);
+    float s = 0.f;   // same fixed order as loss_finalize_kernel
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+        s += __uint_as_float(__hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.loss_out[0] = sh[0] * a.unit;
+        __hip_atomic_store(a.loss_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // one gradient row: atomic add into the dense accumulator, or (REC, m >= 0) a plain 4*D-byte record store
 template <bool REC, int L, int C>
@@ -359,14 +408,7 @@ __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
             ctx_backward<MODEL, L, C, REC>(tm, a, r, cx, Gr, acw, REC ? RS::r * a.n_pos + b : -1, hub);
         }
     }
-    if (tm.lane == 0) red[team_in_block] = lsum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < TEAMS; i++) s += red[i];
-        a.loss_partials[blockIdx.x] = s;
-    }
+    finish_loss<TEAMS>(a, red, lsum, tm.lane, team_in_block);
 }
 
 // fixed-order sum of the per-block partial hinge sums -> loss = sum / denom  (TransE.py:51)
@@ -445,7 +487,7 @@ __global__ __launch_bounds__(256) void transe_emit_kernel(FbArgs a) {
             if (team_sum<L>(bad) != 0.f) {
                 if (tm.lane == 0) {
                     for (long long sl = 0; sl < 3 + a.n_neg; sl++) a.dst[sl * a.n_pos + b] = -1;
-                    a.group_list[atomicAdd(a.group_count, 1)] = (int32_t)b;
+                    if (a.group_list) a.group_list[atomicAdd(a.group_count, 1)] = (int32_t)b;
                 }
                 continue;
             }
@@ -579,14 +621,7 @@ __global__ __launch_bounds__(256) void transe_emit_kernel(FbArgs a) {
             a.dst[2 * a.n_pos + b] = cnt > 0 ? (int32_t)(a.ent_total + r) : -1;
         }
     }
-    if (tm.lane == 0) red[team_in_block] = lsum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < TEAMS; i++) s += red[i];
-        a.loss_partials[blockIdx.x] = s;
-    }
+    finish_loss<TEAMS>(a, red, lsum, tm.lane, team_in_block);
 }
 
 // ---- vectorised, instruction-lean variant (D % 4 == 0) ----------------------------------------------
@@ -653,7 +688,7 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
         if (team_sum<L>(bad) != 0.f) {   // not sampler-shaped: the whole group goes to the exact fp32 kernel
             if (lane == 0) {
                 for (long long sl = 0; sl < 3 + a.n_neg; sl++) a.dst[sl * a.n_pos + b] = -1;
-                a.group_list[atomicAdd(a.group_count, 1)] = (int32_t)b;
+                if (a.group_list) a.group_list[atomicAdd(a.group_count, 1)] = (int32_t)b;
             }
             continue;
         }
@@ -816,14 +851,7 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
             a.dst[2 * a.n_pos + b] = cnt > 0 ? (int32_t)(a.ent_total + r) : -1;
         }
     }
-    if (lane == 0) red[team_in_block] = lsum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < TEAMS; i++) s += red[i];
-        a.loss_partials[blockIdx.x] = s;
-    }
+    finish_loss<TEAMS>(a, red, lsum, lane, team_in_block);
 }
 
 // 1/max(|row|,1e-6): tf.nn.l2_normalize's rsqrt(max(sum x^2, 1e-12)) for every row of the two tables
@@ -842,8 +870,11 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(const float *__restri
 constexpr int kDeferBlocks = 128;
 
 template <int L, int C>
-static void launch_emit(const FbArgs &a, float *d_loss, hipStream_t stream) {
+static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
     constexpr int TEAMS = 256 / L;
+    FbArgs a = a_in;
+    const bool defer_pass = a.g_ent && a.g_rel;   // residual accumulators given: deferred groups get the fp32 pass
+    if (!defer_pass) { a.loss_out = d_loss; a.loss_ticket = engine().dev.loss_ticket; }   // the emit kernel's last block writes the loss
     long long blocks = (a.n_pos + TEAMS - 1) / TEAMS;
     if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
     if (blocks < 1) blocks = 1;
@@ -869,14 +900,25 @@ static void launch_emit(const FbArgs &a, float *d_loss, hipStream_t stream) {
         hipLaunchKernelGGL((transe_emit_kernel<L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
     // groups with non sampler-shaped negatives: exact fp32 path into the residual accumulators
     // (no residual accumulators = record-only caller: the groups stay listed, kge_transe_deferred_groups reports them)
-    if (!a.g_ent || !a.g_rel) {
-        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, a.loss_partials, (int)blocks, a.unit, d_loss);
-        return;
-    }
+    if (!defer_pass) return;
     FbArgs d = a;
     d.loss_partials = a.loss_partials + blocks;
     hipLaunchKernelGGL((fwdbwd_kernel<KGE_TRANSE, L, C>), dim3(kDeferBlocks), dim3(256), 0, stream, d);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, a.loss_partials, (int)blocks + kDeferBlocks, a.unit, d_loss);
+}
+
+int ensure_loss_buffers() {
+    Engine &e = engine();
+    if (!e.dev.loss_partials) {
+        int rc = hip_check(hipMalloc(&e.dev.loss_partials, sizeof(float) * (kMaxLossBlocks + 256)), "alloc loss partials");
+        if (rc) return rc;
+    }
+    if (!e.dev.loss_ticket) {
+        int rc = hip_check(hipMalloc(&e.dev.loss_ticket, sizeof(unsigned)), "alloc loss ticket");
+        if (rc) return rc;
+        if ((rc = hip_check(hipMemset(e.dev.loss_ticket, 0, sizeof(unsigned)), "zero loss ticket"))) return rc;
+    }
+    return KGE_OK;
 }
 
 // team shape used for dimension D (shared with transe_counts.hip through these two helpers)
@@ -899,12 +941,11 @@ int transe_deferred_groups(int32_t *out) {
 
 int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *rel, float *resid_ent, float *resid_rel,
                        const int32_t *d_h, const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
-                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream) {
+                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream, bool track_deferred) {
+    // track_deferred = false: the caller guarantees sampler-shaped negatives (a device-sampled batch): no
+    // deferral list, no counter reset, no fp32 pass
     Engine &e = engine();
-    if (!e.dev.loss_partials) {
-        int rc = hip_check(hipMalloc(&e.dev.loss_partials, sizeof(float) * (kMaxLossBlocks + 256)), "alloc loss partials");
-        if (rc) return rc;
-    }
+    { int rc = ensure_loss_buffers(); if (rc) return rc; }
     int32_t *&defer_list = g_defer_list, *&defer_count = g_defer_count;
     int64_t &defer_cap = g_defer_cap;
     if (n_pos > defer_cap) {
@@ -915,7 +956,7 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
         if (!defer_count && (rc = hip_check(hipMalloc(&defer_count, sizeof(int32_t)), "alloc deferred count"))) return rc;
         defer_cap = n_pos;
     }
-    {
+    if (track_deferred) {
         int rc = hip_check(hipMemsetAsync(defer_count, 0, sizeof(int32_t), stream), "zero deferred count");
         if (rc) return rc;
     }
@@ -931,7 +972,7 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
     }
     FbArgs a = {};
     a.inv_norm = use_inv_table ? inv_norm : nullptr;
-    a.group_list = defer_list; a.group_count = defer_count;
+    a.group_list = track_deferred ? defer_list : nullptr; a.group_count = defer_count;
     a.ent = ent; a.rel = rel; a.g_ent = resid_ent; a.g_rel = resid_rel;
     a.bh = d_h; a.bt = d_t; a.br = d_r;
     a.n_pos = n_pos; a.n_neg = n_neg; a.stride = stride;
@@ -958,8 +999,9 @@ static void launch_fb(const FbArgs &a, float *d_loss, hipStream_t stream) {
     long long blocks = (a.n_pos + TEAMS - 1) / TEAMS;
     if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((fwdbwd_kernel<MODEL, L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, a.loss_partials, (int)blocks, a.unit, d_loss);
+    FbArgs f = a;
+    f.loss_out = d_loss; f.loss_ticket = engine().dev.loss_ticket;   // the last block writes the loss
+    hipLaunchKernelGGL((fwdbwd_kernel<MODEL, L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
 }
 
 template <int MODEL, int L, int C>
@@ -968,8 +1010,9 @@ static void launch_fb_records(const FbArgs &a, float *d_loss, hipStream_t stream
     long long blocks = (a.n_pos + TEAMS - 1) / TEAMS;
     if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((fwdbwd_kernel<MODEL, L, C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, a.loss_partials, (int)blocks, a.unit, d_loss);
+    FbArgs f = a;
+    f.loss_out = d_loss; f.loss_ticket = engine().dev.loss_ticket;
+    hipLaunchKernelGGL((fwdbwd_kernel<MODEL, L, C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
 }
 
 template <int MODEL>
@@ -1028,10 +1071,7 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
     Engine &e = engine();
     if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_forward_backward: no usable HIP device");
     if (n_pos < 0 || n_neg < 1 || stride < n_pos || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_forward_backward: bad sizes");
-    if (!e.dev.loss_partials) {
-        int rc = hip_check(hipMalloc(&e.dev.loss_partials, sizeof(float) * (kMaxLossBlocks + 256)), "alloc loss partials");
-        if (rc) return rc;
-    }
+    { int rc = ensure_loss_buffers(); if (rc) return rc; }
     if (m.model == KGE_TRANSR)
         return launch_forward_backward_transr(m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, grads, d_loss, stream);
     if (m.ent_dim != m.rel_dim) return fail(KGE_ERR_BAD_ARG, "TransE/H/D need ent_dim == rel_dim (hidden_size)");

@@ -11,7 +11,16 @@
 
 namespace kge {
 
-__global__ __launch_bounds__(256) void sgd_kernel(float *__restrict__ p, float *__restrict__ g, long long n, float lr) {
+// up to four tables per launch: blockIdx.y selects the table (one launch per optimizer step instead of one per table)
+struct SweepTables {
+    float *p[4], *g[4], *m[4], *v[4];
+    long long n[4];
+};
+
+__global__ __launch_bounds__(256) void sgd_kernel(SweepTables tb, float lr) {
+    float *__restrict__ p = tb.p[blockIdx.y];
+    float *__restrict__ g = tb.g[blockIdx.y];
+    const long long n = tb.n[blockIdx.y];
     const long long n4 = n >> 2;
     float4 *p4 = reinterpret_cast<float4 *>(p);
     float4 *g4 = reinterpret_cast<float4 *>(g);
@@ -43,9 +52,12 @@ __device__ __forceinline__ void adam_one(float &p, float &m, float &v, float g, 
     p = __fsub_rn(p, __fdiv_rn(__fmul_rn(lr_t, mi), __fadd_rn(__fsqrt_rn(vi), eps)));
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
-                                                   float *__restrict__ g, long long n, float lr_t, float b1, float b2,
-                                                   float eps) {
+__global__ __launch_bounds__(256) void adam_kernel(SweepTables tb, float lr_t, float b1, float b2, float eps) {
+    float *__restrict__ p = tb.p[blockIdx.y];
+    float *__restrict__ m = tb.m[blockIdx.y];
+    float *__restrict__ v = tb.v[blockIdx.y];
+    float *__restrict__ g = tb.g[blockIdx.y];
+    const long long n = tb.n[blockIdx.y];
     const long long n4 = n >> 2;
     float4 *p4 = reinterpret_cast<float4 *>(p), *m4 = reinterpret_cast<float4 *>(m);
     float4 *v4 = reinterpret_cast<float4 *>(v), *g4 = reinterpret_cast<float4 *>(g);
@@ -72,23 +84,53 @@ static unsigned sweep_blocks(long long n) {
     return (unsigned)b;
 }
 
-int launch_sgd(float *p, float *g, int64_t n, float lr, hipStream_t stream) {
+static int check_tables(int n_tables, float *const *p, float *const *g, float *const *m, float *const *v, const int64_t *numel,
+                        SweepTables &tb, long long &n_max, const char *who) {
+    if (n_tables < 1 || n_tables > 4 || !p || !g || !numel) return fail(KGE_ERR_BAD_ARG, std::string(who) + ": 1..4 tables");
+    n_max = 0;
+    for (int i = 0; i < 4; i++) { tb.p[i] = tb.g[i] = tb.m[i] = tb.v[i] = nullptr; tb.n[i] = 0; }
+    for (int i = 0; i < n_tables; i++) {
+        tb.p[i] = p[i]; tb.g[i] = g[i]; tb.m[i] = m ? m[i] : nullptr; tb.v[i] = v ? v[i] : nullptr;
+        tb.n[i] = numel[i] > 0 ? numel[i] : 0;
+        uintptr_t bits = reinterpret_cast<uintptr_t>(p[i]) | reinterpret_cast<uintptr_t>(g[i]);
+        if (m) bits |= reinterpret_cast<uintptr_t>(m[i]) | reinterpret_cast<uintptr_t>(v[i]);
+        if (bits & 15) return fail(KGE_ERR_BAD_ARG, "tables must be 16-byte aligned");
+        if (tb.n[i] > n_max) n_max = tb.n[i];
+    }
+    return KGE_OK;
+}
+
+int launch_sgd_tables(int n_tables, float *const *p, float *const *g, const int64_t *numel, float lr, hipStream_t stream) {
     if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_sgd_update: no usable HIP device");
-    if (n <= 0) return KGE_OK;
-    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g)) & 15) return fail(KGE_ERR_BAD_ARG, "tables must be 16-byte aligned");
-    hipLaunchKernelGGL(sgd_kernel, dim3(sweep_blocks(n)), dim3(256), 0, stream, p, g, (long long)n, lr);
+    SweepTables tb;
+    long long n_max;
+    int rc = check_tables(n_tables, p, g, nullptr, nullptr, numel, tb, n_max, "kge_sgd_update_tables");
+    if (rc) return rc;
+    if (n_max <= 0) return KGE_OK;
+    hipLaunchKernelGGL(sgd_kernel, dim3(sweep_blocks(n_max), (unsigned)n_tables), dim3(256), 0, stream, tb, lr);
     return hip_check(hipGetLastError(), "sgd launch");
+}
+
+int launch_adam_tables(int n_tables, float *const *p, float *const *m, float *const *v, float *const *g, const int64_t *numel,
+                       float lr_t, float b1, float b2, float eps, hipStream_t stream) {
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_adam_update: no usable HIP device");
+    if (!m || !v) return fail(KGE_ERR_BAD_ARG, "kge_adam_update_tables: null moment tables");
+    SweepTables tb;
+    long long n_max;
+    int rc = check_tables(n_tables, p, g, m, v, numel, tb, n_max, "kge_adam_update_tables");
+    if (rc) return rc;
+    if (n_max <= 0) return KGE_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(sweep_blocks(n_max), (unsigned)n_tables), dim3(256), 0, stream, tb, lr_t, b1, b2, eps);
+    return hip_check(hipGetLastError(), "adam launch");
+}
+
+int launch_sgd(float *p, float *g, int64_t n, float lr, hipStream_t stream) {
+    return launch_sgd_tables(1, &p, &g, &n, lr, stream);
 }
 
 int launch_adam(float *p, float *m, float *v, float *g, int64_t n, float lr_t, float b1, float b2, float eps,
                 hipStream_t stream) {
-    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_adam_update: no usable HIP device");
-    if (n <= 0) return KGE_OK;
-    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
-         reinterpret_cast<uintptr_t>(v)) & 15)
-        return fail(KGE_ERR_BAD_ARG, "tables must be 16-byte aligned");
-    hipLaunchKernelGGL(adam_kernel, dim3(sweep_blocks(n)), dim3(256), 0, stream, p, m, v, g, (long long)n, lr_t, b1, b2, eps);
-    return hip_check(hipGetLastError(), "adam launch");
+    return launch_adam_tables(1, &p, &m, &v, &g, &n, lr_t, b1, b2, eps, stream);
 }
 
 }  // namespace kge

@@ -30,7 +30,7 @@ namespace kge {
 void transe_team_shape(int D, int &L, int &C);
 int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *rel, float *resid_ent, float *resid_rel,
                        const int32_t *d_h, const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
-                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream);
+                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream, bool track_deferred);
 
 int transe_deferred_groups(int32_t *out);
 
@@ -480,10 +480,11 @@ struct ApplyArgs {
     int D;
     float unit, lr, b1, b2, eps;
     int adam;
-    // sparse-row form: S is the compact [n_rows, D] image of the rows listed in row_list (one row space:
-    // entity rows, then relation rows at E + r, which live in table p2); SGD only, no residuals
+    // two tables in one launch: rows [0,E) live in p / m / v / resid, rows [E, rows) in p2 / m2 / v2 / resid2
+    // sparse-row form: S is the compact [n_rows, D] image of the rows listed in row_list (same row space);
+    // SGD only, no residuals
     const int32_t *row_list, *n_rows;
-    float *p2;
+    float *p2, *m2, *v2, *resid2;
     long long E;
 };
 
@@ -495,14 +496,11 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
     tm.D = a.D;
     const long long n_rows = SPARSE ? (long long)a.n_rows[0] : a.rows;
     for (long long i = (long long)blockIdx.x * TEAMS + threadIdx.x / L; i < n_rows; i += (long long)gridDim.x * TEAMS) {
-        long long row = i;
-        float *table = a.p;
-        if (SPARSE) {
-            row = a.row_list[i];
-            if (row >= a.E) { row -= a.E; table = a.p2; }
-        }
+        long long row = SPARSE ? (long long)a.row_list[i] : i;
+        float *table = a.p, *mt = a.m, *vt = a.v, *rt = a.resid;
+        if (row >= a.E) { row -= a.E; table = a.p2; mt = a.m2; vt = a.v2; rt = a.resid2; }
         int32_t *Sp = a.S + i * a.D;
-        float *rp = SPARSE ? nullptr : a.resid + row * a.D;
+        float *rp = SPARSE ? nullptr : rt + row * a.D;
         float s[C], rs[C];
         float touched = 0.f;
 #pragma unroll
@@ -534,7 +532,7 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
             const int e = tm.lane + L * c;
             if (e >= a.D) continue;
             if (!SPARSE && a.adam) {
-                float *mp = a.m + row * a.D + e, *vp = a.v + row * a.D + e;
+                float *mp = mt + row * a.D + e, *vp = vt + row * a.D + e;
                 float mi = __fmul_rn(*mp, a.b1), vi = __fmul_rn(*vp, a.b2);
                 if (g[c] != 0.f) {
                     mi = __fadd_rn(mi, __fmul_rn(g[c], 1.0f - a.b1));
@@ -590,7 +588,7 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
     const int rows = (int)(m->ent_total + m->rel_total);
     // krel = 1: relation rows are ordinary rows E + r of the one row space (hub rows are split by the chunking)
     rc = launch_transe_emit(*m, d_ent, d_rel, d_resid_ent, d_resid_rel, d_h, d_t, d_r, n_pos, n_neg, stride, denom, g_c.rec, g_c.dst,
-                            1, d_loss, stream);
+                            1, d_loss, stream, d_resid_ent != nullptr && d_resid_rel != nullptr);
     if (rc) return rc;
     const int D = m->ent_dim;
     const bool nat = D % 4 == 0;   // the vectorised emit kernel writes records in natural element order
@@ -663,7 +661,7 @@ int kge_transe_emit_records(const kge_model_desc *m, const float *d_ent, const f
     if (n_pos < 0 || stride < n_pos || denom <= 0 || !d_rec || !d_dst) return fail(KGE_ERR_BAD_ARG, "kge_transe_emit_records: bad arguments");
     if (n_pos == 0) return hip_check(hipMemsetAsync(d_loss, 0, sizeof(float), stream), "zero loss");
     return launch_transe_emit(*m, d_ent, d_rel, d_resid_ent, d_resid_rel, d_h, d_t, d_r, n_pos, n_neg, stride, denom, d_rec, d_dst, 1,
-                              d_loss, stream);
+                              d_loss, stream, true);
 }
 
 int kge_transe_deferred_groups(int32_t *n_groups) {
@@ -751,8 +749,8 @@ int kge_transe_apply_counts(float *d_p, float *d_m, float *d_v, int32_t *d_count
     if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_apply_counts: no usable HIP device");
     if (rows <= 0) return KGE_OK;
     if (dim > 1024 || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_counts: bad sizes");
-    ApplyArgs a;
-    a.p = d_p; a.m = d_m; a.v = d_v; a.S = d_counts; a.resid = d_resid; a.rows = rows; a.D = dim;
+    ApplyArgs a = {};
+    a.p = d_p; a.m = d_m; a.v = d_v; a.S = d_counts; a.resid = d_resid; a.rows = rows; a.D = dim; a.E = rows;
     a.unit = 1.0f / (float)denom; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.adam = adam;
     const int D = dim;
 #define KGE_APPLY(LL, CC)                                                                                   \
@@ -763,6 +761,34 @@ int kge_transe_apply_counts(float *d_p, float *d_m, float *d_v, int32_t *d_count
     }
     KGE_SHAPE_DISPATCH(D, KGE_APPLY)
 #undef KGE_APPLY
+    return hip_check(hipGetLastError(), "apply counts launch");
+}
+
+int kge_transe_apply_counts_tables(const kge_model_desc *m, float *const d_p[2], float *const d_m[2], float *const d_v[2],
+                                   int32_t *d_counts, float *const d_resid[2], INT denom, int32_t adam, float lr, float beta1,
+                                   float beta2, float eps, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_apply_counts_tables: no usable HIP device");
+    if (!m || !d_p || !d_p[0] || !d_p[1] || !d_counts || !d_resid || !d_resid[0] || !d_resid[1] || denom <= 0)
+        return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_counts_tables: bad arguments");
+    if (adam && (!d_m || !d_v || !d_m[0] || !d_m[1] || !d_v[0] || !d_v[1]))
+        return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_counts_tables: Adam needs the moment tables");
+    const long long rows = m->ent_total + m->rel_total;
+    if (rows <= 0) return KGE_OK;
+    ApplyArgs a = {};
+    a.p = d_p[0]; a.p2 = d_p[1]; a.resid = d_resid[0]; a.resid2 = d_resid[1];
+    if (adam) { a.m = d_m[0]; a.m2 = d_m[1]; a.v = d_v[0]; a.v2 = d_v[1]; }
+    a.S = d_counts; a.rows = rows; a.E = m->ent_total; a.D = m->ent_dim;
+    a.unit = 1.0f / (float)denom; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.adam = adam;
+    const int D = m->ent_dim;
+#define KGE_APPLY2(LL, CC)                                                                                  \
+    {                                                                                                       \
+        long long nb = (rows + (256 / LL) - 1) / (256 / LL);                                                \
+        if (nb > 8192) nb = 8192;                                                                           \
+        hipLaunchKernelGGL((apply_counts_kernel<LL, CC, false>), dim3((unsigned)nb), dim3(256), 0, stream, a); \
+    }
+    KGE_SHAPE_DISPATCH(D, KGE_APPLY2)
+#undef KGE_APPLY2
     return hip_check(hipGetLastError(), "apply counts launch");
 }
 
