@@ -284,7 +284,11 @@ class Config(object):
         self._dev_batch = None
         self._side_stream = None
         self._prefetched = None
-        self.prefetch_sampling = bool(getattr(self, "prefetch_sampling", False))  # measured: no gain at 1 GPU (the sampler competes with segsum/apply)
+        # None = automatic: off at 1 GPU (measured: the sampler then competes with segsum/apply for the same CUs),
+        # on in data-parallel runs, where batch i+1 is drawn while step i's gradient all-reduce waits on the wire
+        self.prefetch_sampling = getattr(self, "prefetch_sampling", None)
+        if self.prefetch_sampling is None and self.world_size > 1:
+            self.prefetch_sampling = True
         self.global_step = 0
         self._sparse_buf = None
         # TransE steps with fewer gradient rows than this take the single fused fp32-atomic kernel (launch-bound
@@ -305,6 +309,8 @@ class Config(object):
         self.world_size = dist.get_world_size(process_group)
         if self.trainModel is not None:
             self._setup_partition()
+        if getattr(self, "prefetch_sampling", None) is None and self.world_size > 1:
+            self.prefetch_sampling = True
 
     def _setup_partition(self):
         from .parallel import thread_range

@@ -12,7 +12,7 @@ from conftest import GOLDEN, ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir, model_name, opt, sparse=False):
+def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -26,6 +26,7 @@ def _worker(rank, world, port, out_dir, model_name, opt, sparse=False):
     con.set_work_threads(8); con.set_bern(1); con.set_dimension(48); con.set_nbatches(10)  # B = 600
     con.set_ent_neg_rate(3); con.set_alpha(0.02); con.set_opt_method(opt)
     con.sparse_rows = sparse
+    con.prefetch_sampling = prefetch   # (data-parallel default: on; then the rng states run one batch ahead)
     con.counts_min_records = 0
     con.init()
     con.set_model_and_session(getattr(pkg, model_name))
@@ -77,3 +78,20 @@ def test_two_ranks_sparse_record_exchange(tmp_path):
             continue
         assert np.array_equal(r0[k], r1[k]), k
         assert np.array_equal(r0[k], one[k]), k
+
+
+def test_two_ranks_with_prefetched_sampling(tmp_path):
+    """The data-parallel default draws batch i+1 during step i's all-reduce: same tables as without."""
+    import torch.multiprocessing as mp
+    port = 29800 + os.getpid() % 1000
+    mp.start_processes(_worker, args=(1, port, str(tmp_path), "TransE", "Adam", False, False), nprocs=1, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(2, port + 1, str(tmp_path), "TransE", "Adam", False, None), nprocs=2, join=True, start_method="spawn")
+    one = np.load(str(tmp_path / "w1_r0.npz"))
+    r0 = np.load(str(tmp_path / "w2_r0.npz"))
+    r1 = np.load(str(tmp_path / "w2_r1.npz"))
+    assert np.allclose(r0["losses"], one["losses"], rtol=2e-5, atol=0)
+    for k in one.files:
+        if k in ("losses", "states"):
+            continue
+        assert np.array_equal(r0[k], r1[k]), k
+        assert np.array_equal(r0[k], one[k]), k    # integer counts: bit-identical to the single-process run
