@@ -17,6 +17,7 @@
 //
 // FLOPs per scored triple: fwd 2 projections 4.de.dr, bwd 8.de.dr.
 #include <cstring>
+#include <type_traits>
 #include <string.h>
 
 #include <rocprim/rocprim.hpp>
@@ -115,7 +116,9 @@ __global__ void prep_kernel(const int32_t *__restrict__ bh, const int32_t *__res
 // bucket_start[r] = first sorted position with key >= r (r = 0..R+1), then the (relation, row tile) map
 __global__ __launch_bounds__(1024) void bounds_kernel(const int32_t *__restrict__ sorted_keys, int J, int R,
                                                       int32_t *__restrict__ bucket_start, int32_t *__restrict__ tile_rel,
-                                                      int32_t *__restrict__ tile_row0, int32_t *__restrict__ n_tiles) {
+                                                      int32_t *__restrict__ tile_row0, int32_t *__restrict__ n_tiles, int tile_shift) {
+    // tile_shift: log2 of the rows per tile (5 = the 32-row tiles of rows_gemm_kernel, 7 = the 128-row tiles of the v2 kernels)
+    const int tile_rows = 1 << tile_shift;
     __shared__ int chunk_tiles[1024];
     for (int r = threadIdx.x; r <= R + 1; r += blockDim.x) {
         int lo = 0, hi = J;
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(1024) void bounds_kernel(const int32_t *__restrict_
     const int per = (R + (int)blockDim.x - 1) / (int)blockDim.x;
     const int r0 = threadIdx.x * per, r1 = min(R, r0 + per);
     int mine = 0;
-    for (int r = r0; r < r1; r++) mine += (bucket_start[r + 1] - bucket_start[r] + 31) >> 5;
+    for (int r = r0; r < r1; r++) mine += (bucket_start[r + 1] - bucket_start[r] + tile_rows - 1) >> tile_shift;
     chunk_tiles[threadIdx.x] = mine;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(1024) void bounds_kernel(const int32_t *__restrict_
     __syncthreads();
     int t = chunk_tiles[threadIdx.x];
     for (int r = r0; r < r1; r++)
-        for (int row = bucket_start[r]; row < bucket_start[r + 1]; row += 32) { tile_rel[t] = r; tile_row0[t] = row; t++; }
+        for (int row = bucket_start[r]; row < bucket_start[r + 1]; row += tile_rows) { tile_rel[t] = r; tile_row0[t] = row; t++; }
 }
 
 // predict: every triple uses the matrix of predict_r[0] (TransR.py:83): one bucket holding all slots
@@ -261,12 +264,13 @@ __device__ __forceinline__ void wgrad_flush(const GemmArgs &a, float *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_kernel(GemmArgs a, float *__restrict__ g_mat, int tiles_i) {
+__global__ __launch_bounds__(256) void wgrad_kernel(GemmArgs a, float *__restrict__ g_mat, int tiles_i, int tile_rows, int wg_tiles) {
+    // tile_rows: height of the tiles in the map (32, or 128 when the map was built for the v2 kernels)
     const int grp = blockIdx.x / tiles_i, it = blockIdx.x - grp * tiles_i;
     const int n_tiles = a.n_tiles[0];
-    const int t0 = grp * WG_TILES;
+    const int t0 = grp * wg_tiles;
     if (t0 >= n_tiles) return;
-    const int t1 = min(t0 + WG_TILES, n_tiles);
+    const int t1 = min(t0 + wg_tiles, n_tiles);
     __shared__ float As[KC][32 + 1];
     __shared__ float Bs[KC][TN + 1];
     __shared__ int s_slot[KC], s_ent[KC];
@@ -282,32 +286,352 @@ __global__ __launch_bounds__(256) void wgrad_kernel(GemmArgs a, float *__restric
             acc = f32x16{0};
             r_cur = r;
         }
-        const int row0 = a.tile_row0[t];
-        const int rows = min(32, a.bucket_start[r + 1] - row0);
-        __syncthreads();
-        if (tid < KC) {
-            int sl = tid < rows ? a.sorted_slots[row0 + tid] : -1;
-            s_slot[tid] = sl;
-            s_ent[tid] = sl >= 0 ? a.job_ent[sl] : -1;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < KC * 32; idx += 256) {
-            const int kk = idx >> 5, i = idx & 31;
-            As[kk][i] = (kk < rows && i0 + i < a.De) ? a.ent[(long long)s_ent[kk] * a.De + i0 + i] : 0.f;
-        }
-        for (int idx = tid; idx < KC * TN; idx += 256) {
-            const int kk = idx / TN, j = idx - kk * TN;
-            Bs[kk][j] = (kk < rows && j0 + j < a.Dr) ? a.GP[(long long)s_slot[kk] * a.Dr + j0 + j] : 0.f;
-        }
-        __syncthreads();
+        const int trow0 = a.tile_row0[t];
+        const int trows = min(tile_rows, a.bucket_start[r + 1] - trow0);
+        for (int c0 = 0; c0 < trows; c0 += 32) {
+            const int row0 = trow0 + c0;
+            const int rows = min(32, trows - c0);
+            __syncthreads();
+            if (tid < KC) {
+                int sl = tid < rows ? a.sorted_slots[row0 + tid] : -1;
+                s_slot[tid] = sl;
+                s_ent[tid] = sl >= 0 ? a.job_ent[sl] : -1;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < KC * 32; idx += 256) {
+                const int kk = idx >> 5, i = idx & 31;
+                As[kk][i] = (kk < rows && i0 + i < a.De) ? a.ent[(long long)s_ent[kk] * a.De + i0 + i] : 0.f;
+            }
+            for (int idx = tid; idx < KC * TN; idx += 256) {
+                const int kk = idx / TN, j = idx - kk * TN;
+                Bs[kk][j] = (kk < rows && j0 + j < a.Dr) ? a.GP[(long long)s_slot[kk] * a.Dr + j0 + j] : 0.f;
+            }
+            __syncthreads();
 #pragma unroll
-        for (int k2 = 0; k2 < KC; k2 += 2) {
-            const float av = As[k2 + (lane >> 5)][lane & 31];
-            const float bv = Bs[k2 + (lane >> 5)][wave * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            for (int k2 = 0; k2 < KC; k2 += 2) {
+                const float av = As[k2 + (lane >> 5)][lane & 31];
+                const float bv = Bs[k2 + (lane >> 5)][wave * 32 + (lane & 31)];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
         }
     }
     wgrad_flush(a, g_mat, r_cur, i0, jg, lane, acc);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// v2 tiles (training path): v_mfma_f32_16x16x4_f32, 16-wide granularity so that dim 200 pads to 208 (4 %)
+// instead of 256 (28 %), 64-row tiles per workgroup (each wave owns 16 rows and ALL <= 13 column tiles, so a
+// relation's matrix is read once per 64 rows), operands staged in LDS in layouts whose MFMA reads are
+// bank-conflict free:
+//   A operand: lane l supplies A[i = l&15][k = l>>4];  B operand: B[k = l>>4][j = l&15];
+//   accumulator reg v of lane l holds D[i = 4*(l>>4) + v][j = l&15].
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: the staging register arrays must only ever be indexed by constants (a rolled loop sends them to scratch)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+constexpr int RM2 = 64;          // rows per workgroup
+constexpr int KC2 = 40;          // K chunk: 10 MFMA k-steps
+constexpr int NT2 = 13;          // 16-column tiles per workgroup: 208 columns
+constexpr int LDA2 = KC2 + 2;    // [i][k] layout, stride 42: lanes (i, k..k+1) hit 32 distinct banks
+constexpr int LDB2 = NT2 * 16;   // [k][j] layout, stride 208 = 16 mod 32: lanes (k..k+1, j) hit 32 distinct banks
+
+// Staging: every thread issues ALL its global loads of a chunk back to back into registers (unconditional, with
+// clamped addresses -- the compiler serialises conditional loads, one memory latency each), the chunk after the one
+// being multiplied is in flight during the MFMA loop, and invalid elements are zeroed on the way into LDS.
+// VEC (both dims multiples of 4): 16-byte loads; otherwise a scalar, conditional fallback (odd test shapes).
+// RT2 16-row sub-tiles per wave: a workgroup covers 64*RT2 rows, so a relation's 160 kB matrix (which comes from the
+// Infinity Cache, not HBM) is re-read once per 128 rows: 39 flop per byte instead of 24.
+constexpr int RT2 = 2;
+constexpr int RW2 = RM2 * RT2;   // rows per workgroup (128)
+
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(256) void rows_gemm2_kernel(GemmArgs a) {
+    const int tile = blockIdx.x;
+    if (tile >= a.n_tiles[0]) return;
+    __shared__ __attribute__((aligned(16))) float As[RW2 * LDA2];
+    __shared__ __attribute__((aligned(16))) float Bs[(MODE == GEMM_PROJECT) ? KC2 * LDB2 : LDB2 * LDA2];
+    __shared__ int s_slot[RW2], s_ent[RW2];
+    const int r = a.tile_rel[tile];
+    const int row0 = a.tile_row0[tile];
+    const int rows = min(RW2, a.bucket_start[r + 1] - row0);
+    const int K = MODE == GEMM_PROJECT ? a.De : a.Dr;
+    const int N = MODE == GEMM_PROJECT ? a.Dr : a.De;
+    const int ncols = min(LDB2, N);
+    const int nt = (ncols + 15) >> 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < RW2) {
+        int sl = a.sorted_slots[row0 + min(tid, rows - 1)];   // padding rows repeat the last live row (never stored)
+        s_slot[tid] = sl;
+        s_ent[tid] = a.job_ent[sl];
+    }
+    __syncthreads();
+    const float *M = a.mat + (long long)r * a.De * a.Dr;
+    f32x4 acc[RT2][NT2];
+#pragma unroll
+    for (int s2 = 0; s2 < RT2; s2++)
+#pragma unroll
+        for (int t = 0; t < NT2; t++) acc[s2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // sub-tile s2 of wave w covers rows (4*s2 + w)*16 ..: interleaved, so a short tile keeps all four waves busy
+    constexpr int AQ = KC2 / 4;                       // float4 per A row chunk
+    constexpr int NA = (RW2 * AQ + 255) / 256;        // A float4 loads per thread (5)
+    constexpr int BROWS = MODE == GEMM_PROJECT ? KC2 : LDB2;
+    constexpr int BQ = MODE == GEMM_PROJECT ? LDB2 / 4 : KC2 / 4;
+    constexpr int NB = (BROWS * BQ + 255) / 256;      // B float4 loads per thread (9)
+    float4 ra[NA], rb[NB];
+#define KGE_LOAD_CHUNK(k0_)                                                                                                  \
+    {                                                                                                                        \
+        static_for<0, NA>([&](auto uc) {                                                                                     \
+            constexpr int u = decltype(uc)::value;                                                                           \
+            const int idx = min(tid + 256 * u, RW2 * AQ - 1);                                                                \
+            const int i = idx / AQ, q = idx - i * AQ;                                                                        \
+            const int kg = min((k0_) + 4 * q, K - 4);                                                                        \
+            const float *src = MODE == GEMM_PROJECT ? a.ent + (long long)s_ent[i] * a.De + kg                                \
+                                                    : a.GP + (long long)s_slot[i] * a.Dr + kg;                               \
+            ra[u] = *reinterpret_cast<const float4 *>(src);                                                                  \
+        });                                                                                                                  \
+        static_for<0, NB>([&](auto uc) {                                                                                     \
+            constexpr int u = decltype(uc)::value;                                                                           \
+            const int idx = min(tid + 256 * u, BROWS * BQ - 1);                                                              \
+            const int rr = idx / BQ, q = idx - rr * BQ;                                                                      \
+            const float *src = MODE == GEMM_PROJECT ? M + (long long)min((k0_) + rr, K - 1) * a.Dr + min(4 * q, ncols - 4)   \
+                                                    : M + (long long)min(rr, ncols - 1) * a.Dr + min((k0_) + 4 * q, K - 4);  \
+            rb[u] = *reinterpret_cast<const float4 *>(src);                                                                  \
+        });                                                                                                                  \
+    }
+    if (VEC) KGE_LOAD_CHUNK(0)
+    for (int k0 = 0; k0 < K; k0 += KC2) {
+        if (k0 > 0) __syncthreads();          // the previous chunk's MFMA reads are done
+        if (VEC) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            static_for<0, NA>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int idx = tid + 256 * u;
+                if (idx < RW2 * AQ) {
+                    const int i = idx / AQ, q = idx - i * AQ;
+                    const float4 v = (i < rows && k0 + 4 * q < K) ? ra[u] : z;
+                    float2 *dst = reinterpret_cast<float2 *>(&As[i * LDA2 + 4 * q]);   // stride 42 floats: 8-byte aligned
+                    dst[0] = make_float2(v.x, v.y);
+                    dst[1] = make_float2(v.z, v.w);
+                }
+            });
+            static_for<0, NB>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int idx = tid + 256 * u;
+                if (idx < BROWS * BQ) {
+                    const int rr = idx / BQ, q = idx - rr * BQ;
+                    if (MODE == GEMM_PROJECT) {
+                        *reinterpret_cast<float4 *>(&Bs[rr * LDB2 + 4 * q]) = (k0 + rr < K && 4 * q < ncols) ? rb[u] : z;
+                    } else {
+                        const float4 v = (rr < ncols && k0 + 4 * q < K) ? rb[u] : z;
+                        float2 *dst = reinterpret_cast<float2 *>(&Bs[rr * LDA2 + 4 * q]);
+                        dst[0] = make_float2(v.x, v.y);
+                        dst[1] = make_float2(v.z, v.w);
+                    }
+                }
+            });
+        } else {   // scalar fallback for dims that are not multiples of 4
+            for (int idx = tid; idx < RW2 * KC2; idx += 256) {
+                const int i = idx / KC2, kk = idx - i * KC2, kg = k0 + kk;
+                float v = 0.f;
+                if (i < rows && kg < K)
+                    v = MODE == GEMM_PROJECT ? a.ent[(long long)s_ent[i] * a.De + kg] : a.GP[(long long)s_slot[i] * a.Dr + kg];
+                As[i * LDA2 + kk] = v;
+            }
+            if (MODE == GEMM_PROJECT) {
+                for (int idx = tid; idx < KC2 * LDB2; idx += 256) {
+                    const int kk = idx / LDB2, j = idx - kk * LDB2, kg = k0 + kk;
+                    Bs[kk * LDB2 + j] = (kg < K && j < ncols) ? M[(long long)kg * a.Dr + j] : 0.f;
+                }
+            } else {
+                for (int idx = tid; idx < LDB2 * KC2; idx += 256) {
+                    const int j = idx / KC2, kk = idx - j * KC2, kg = k0 + kk;
+                    Bs[j * LDA2 + kk] = (kg < K && j < ncols) ? M[(long long)j * a.Dr + kg] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (VEC && k0 + KC2 < K) KGE_LOAD_CHUNK(k0 + KC2)   // in flight during the MFMA loop
+#pragma unroll
+        for (int ks = 0; ks < KC2; ks += 4) {
+            const int kk = ks + (lane >> 4);
+            float av[RT2];
+#pragma unroll
+            for (int s2 = 0; s2 < RT2; s2++) av[s2] = As[((4 * s2 + wave) * 16 + (lane & 15)) * LDA2 + kk];
+#pragma unroll
+            for (int t = 0; t < NT2; t++) {
+                if (t < nt) {
+                    const float bv = MODE == GEMM_PROJECT ? Bs[kk * LDB2 + t * 16 + (lane & 15)] : Bs[(t * 16 + (lane & 15)) * LDA2 + kk];
+#pragma unroll
+                    for (int s2 = 0; s2 < RT2; s2++)
+                        if ((4 * s2 + wave) * 16 < rows) acc[s2][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv, acc[s2][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#undef KGE_LOAD_CHUNK
+#pragma unroll
+    for (int s2 = 0; s2 < RT2; s2++) {
+        if ((4 * s2 + wave) * 16 >= rows) continue;
+#pragma unroll
+        for (int t = 0; t < NT2; t++) {
+            const int j = t * 16 + (lane & 15);
+            if (t < nt && j < ncols) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int row = (4 * s2 + wave) * 16 + 4 * (lane >> 4) + v;
+                    if (row < rows) {
+                        if (MODE == GEMM_PROJECT) a.P[(long long)s_slot[row] * a.Dr + j] = acc[s2][t][v];
+                        else __builtin_amdgcn_global_atomic_fadd_f32(
+                                (__attribute__((address_space(1))) float *)(a.g_ent + (long long)s_ent[row] * a.De + j), acc[s2][t][v]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// wgrad v2: g_M[r][i][j] += sum over rows of ent[e_row][i] * GP[slot_row][j].  A workgroup owns SPAN2 consecutive
+// 128-row tiles of the relation-sorted job list (256 rows between flushes) and ALL <= 13 x 13 output tiles, so the
+// rows are streamed exactly once; wave w takes output row-tiles w, w+4, w+8, w+12 and every column tile.
+// Rows are staged 32 at a time, the next 32 in flight during the MFMA loop.
+constexpr int SPAN2 = 2;
+constexpr int WK2 = 32;                 // rows per staged chunk (8 k-steps)
+constexpr int WI2 = 4;                  // output row-tiles per wave: ceil(13 / 4)
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void wgrad2_kernel(GemmArgs a, float *__restrict__ g_mat) {
+    const int n_tiles = a.n_tiles[0];
+    const int t0 = blockIdx.x * SPAN2;
+    if (t0 >= n_tiles) return;
+    const int t1 = min(t0 + SPAN2, n_tiles);
+    __shared__ __attribute__((aligned(16))) float Xs[WK2 * LDB2];    // [row k][i], stride 208
+    __shared__ __attribute__((aligned(16))) float Gs[WK2 * LDB2];    // [row k][j]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nti = (a.De + 15) >> 4, ntj = (a.Dr + 15) >> 4;
+    f32x4 acc[WI2][NT2];
+#pragma unroll
+    for (int s2 = 0; s2 < WI2; s2++)
+#pragma unroll
+        for (int t2 = 0; t2 < NT2; t2++) acc[s2][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int Q = LDB2 / 4;                       // float4 per staged row (52)
+    constexpr int NL = (WK2 * Q + 255) / 256;         // float4 loads per thread and operand (7)
+    float4 rx[NL], rg[NL];
+    const int qx = a.De / 4, qg = a.Dr / 4;           // valid float4 per row (VEC only)
+#define KGE_WLOAD(row_first_, crow_)                                                                          \
+    {                                                                                                         \
+        static_for<0, NL>([&](auto uc) {                                                                      \
+            constexpr int u = decltype(uc)::value;                                                            \
+            const int idx = min(tid + 256 * u, WK2 * Q - 1);                                                  \
+            const int kk = idx / Q, q = idx - kk * Q;                                                         \
+            const int sl = a.sorted_slots[(row_first_) + min(kk, (crow_) - 1)];                               \
+            const int e = a.job_ent[sl];                                                                      \
+            rx[u] = *reinterpret_cast<const float4 *>(a.ent + (long long)e * a.De + 4 * min(q, qx - 1));      \
+            rg[u] = *reinterpret_cast<const float4 *>(a.GP + (long long)sl * a.Dr + 4 * min(q, qg - 1));      \
+        });                                                                                                   \
+    }
+#define KGE_WFLUSH(rel_)                                                                                      \
+    {                                                                                                         \
+        float *G = g_mat + (long long)(rel_) * a.De * a.Dr;                                                   \
+        _Pragma("unroll") for (int s2 = 0; s2 < WI2; s2++) {                                                  \
+            _Pragma("unroll") for (int t2 = 0; t2 < NT2; t2++) {                                              \
+                const int j = t2 * 16 + (lane & 15);                                                          \
+                if (wave + 4 * s2 < nti && t2 < ntj) {                                                        \
+                    _Pragma("unroll") for (int v = 0; v < 4; v++) {                                           \
+                        const int i = (wave + 4 * s2) * 16 + 4 * (lane >> 4) + v;                             \
+                        if (i < a.De && j < a.Dr && acc[s2][t2][v] != 0.f)                                    \
+                            __builtin_amdgcn_global_atomic_fadd_f32(                                          \
+                                (__attribute__((address_space(1))) float *)(G + (long long)i * a.Dr + j), acc[s2][t2][v]); \
+                    }                                                                                         \
+                }                                                                                             \
+                acc[s2][t2] = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+    int t = t0, c0 = 0;
+    int rel = a.tile_rel[t];
+    int r_cur = rel;
+    int rows_t = min(RW2, a.bucket_start[rel + 1] - a.tile_row0[t]);
+    int row_first = a.tile_row0[t];
+    int crow = min(WK2, rows_t);
+    if (VEC) KGE_WLOAD(row_first, crow)
+    bool first = true;
+    while (true) {
+        if (rel != r_cur) {
+            KGE_WFLUSH(r_cur)
+            r_cur = rel;
+        }
+        if (!first) __syncthreads();
+        first = false;
+        if (VEC) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            static_for<0, NL>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int idx = tid + 256 * u;
+                if (idx < WK2 * Q) {
+                    const int kk = idx / Q, q = idx - kk * Q;
+                    *reinterpret_cast<float4 *>(&Xs[kk * LDB2 + 4 * q]) = (kk < crow && q < qx) ? rx[u] : z;
+                    *reinterpret_cast<float4 *>(&Gs[kk * LDB2 + 4 * q]) = (kk < crow && q < qg) ? rg[u] : z;
+                }
+            });
+        } else {
+            for (int idx = tid; idx < WK2 * LDB2; idx += 256) {
+                const int kk = idx / LDB2, c = idx - kk * LDB2;
+                float x = 0.f, gv = 0.f;
+                if (kk < crow) {
+                    const int sl = a.sorted_slots[row_first + kk];
+                    if (c < a.De) x = a.ent[(long long)a.job_ent[sl] * a.De + c];
+                    if (c < a.Dr) gv = a.GP[(long long)sl * a.Dr + c];
+                }
+                Xs[idx] = x;
+                Gs[idx] = gv;
+            }
+        }
+        __syncthreads();
+        // the next chunk: same tile, or the first chunk of the next tile of the span
+        int nt_ = t, nc = c0 + WK2;
+        if (nc >= rows_t) { nt_ = t + 1; nc = 0; }
+        const bool more = nt_ < t1;
+        int n_first = 0, n_crow = 1, n_rel = rel, n_rows = rows_t;
+        if (more) {
+            n_rel = a.tile_rel[nt_];
+            const int nrow0 = a.tile_row0[nt_];
+            n_rows = min(RW2, a.bucket_start[n_rel + 1] - nrow0);
+            n_first = nrow0 + nc;
+            n_crow = min(WK2, n_rows - nc);
+            if (VEC) KGE_WLOAD(n_first, n_crow)
+        }
+#pragma unroll
+        for (int ks = 0; ks < WK2; ks += 4) {
+            const int kk = ks + (lane >> 4);
+            float av[WI2];
+#pragma unroll
+            for (int s2 = 0; s2 < WI2; s2++) av[s2] = Xs[kk * LDB2 + min(wave + 4 * s2, NT2 - 1) * 16 + (lane & 15)];   // A[i][k] = X[row k][i]
+#pragma unroll
+            for (int t2 = 0; t2 < NT2; t2++) {
+                if (t2 < ntj) {
+                    const float bv = Gs[kk * LDB2 + t2 * 16 + (lane & 15)];   // B[k][j] = GP[row k][j]
+#pragma unroll
+                    for (int s2 = 0; s2 < WI2; s2++)
+                        if (wave + 4 * s2 < nti) acc[s2][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv, acc[s2][t2], 0, 0, 0);
+                }
+            }
+        }
+        if (!more) break;
+        t = nt_; c0 = nc; row_first = n_first; crow = n_crow; rel = n_rel; rows_t = n_rows;
+    }
+    KGE_WFLUSH(r_cur)
+#undef KGE_WLOAD
+#undef KGE_WFLUSH
 }
 
 int bits_for(int64_t v) { int b = 1; while ((int64_t(1) << b) <= v) b++; return b; }
@@ -333,24 +657,46 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     rc = hip_check(rocprim::radix_sort_pairs(g_w.sort_tmp, tmp, g_w.keys, g_w.keys2, g_w.vals, g_w.vals2, (size_t)slots, 0,
                                              bits_for(R), stream), "transr bucket sort");
     if (rc) return rc;
+    // v2 kernels (16x16x4 MFMA, 64-row tiles) whenever one workgroup covers all columns of both dimensions
+    const bool v2 = De <= LDB2 && Dr <= LDB2 && engine().transr_v1 != 1;
     hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(1024), 0, stream, g_w.keys2, (int)slots, (int)R, g_w.bucket_start,
-                       g_w.tile_rel, g_w.tile_row0, g_w.n_tiles);
+                       g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, v2 ? 7 : 5);
     GemmArgs ga;
     ga.ent = tables[0]; ga.mat = tables[2]; ga.GP = g_w.GP; ga.P = g_w.P; ga.g_ent = grads[0];
     ga.sorted_slots = g_w.vals2; ga.job_ent = g_w.job_ent; ga.bucket_start = g_w.bucket_start;
     ga.tile_rel = g_w.tile_rel; ga.tile_row0 = g_w.tile_row0; ga.n_tiles = g_w.n_tiles;
     ga.De = De; ga.Dr = Dr;
-    const unsigned max_tiles = (unsigned)(slots / 32 + R + 1);
-    hipLaunchKernelGGL((rows_gemm_kernel<GEMM_PROJECT>), dim3(max_tiles, (Dr + TN - 1) / TN), dim3(256), 0, stream, ga);
+    const unsigned max_tiles = (unsigned)(slots / (v2 ? RW2 : 32) + R + 1);
+    const bool vec = De % 4 == 0 && Dr % 4 == 0;
+    if (v2 && vec) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, true>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
+    else if (v2) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, false>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
+    else hipLaunchKernelGGL((rows_gemm_kernel<GEMM_PROJECT>), dim3(max_tiles, (Dr + TN - 1) / TN), dim3(256), 0, stream, ga);
     rc = hip_check(hipMemsetAsync(g_w.GP, 0, sizeof(float) * (size_t)slots * Dr, stream), "zero GP");
     if (rc) return rc;
     rc = launch_transr_vector_stage(tables[1], grads[1], g_w.P, g_w.GP, d_h, d_t, d_r, n_pos, n_neg, stride, denom, Dr, m.margin,
                                     m.negative_rel, d_loss, stream);
     if (rc) return rc;
+    if (v2) {
+        const dim3 wg((max_tiles + SPAN2 - 1) / SPAN2, 1);
+        if (vec) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, true>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
+        else hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, false>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
+        // the all-output-tiles wgrad pays one 160 kB atomic flush per relation change: only with well-filled buckets
+        // (measured: 316 vs 400 us at 574 rows per relation, 131 vs 77 us at 46)
+        if (slots >= 256 * R || engine().transr_v1 == 2) {
+            if (vec) hipLaunchKernelGGL((wgrad2_kernel<true>), wg, dim3(256), 0, stream, ga, grads[2]);
+            else hipLaunchKernelGGL((wgrad2_kernel<false>), wg, dim3(256), 0, stream, ga, grads[2]);
+        } else {
+            const int tiles_i1 = (De + 31) / 32;
+            const int wgt = WG_TILES * 32 / RW2;   // the same 256 rows between flushes as with 32-row tiles
+            const unsigned groups1 = (max_tiles + wgt - 1) / wgt;
+            hipLaunchKernelGGL(wgrad_kernel, dim3(groups1 * tiles_i1, (Dr + TN - 1) / TN), dim3(256), 0, stream, ga, grads[2], tiles_i1, RW2, wgt);
+        }
+        return hip_check(hipGetLastError(), "transr launch");
+    }
     hipLaunchKernelGGL((rows_gemm_kernel<GEMM_DGRAD>), dim3(max_tiles, (De + TN - 1) / TN), dim3(256), 0, stream, ga);
     const int tiles_i = (De + 31) / 32;
     const unsigned groups = (max_tiles + WG_TILES - 1) / WG_TILES;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(groups * tiles_i, (Dr + TN - 1) / TN), dim3(256), 0, stream, ga, grads[2], tiles_i);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(groups * tiles_i, (Dr + TN - 1) / TN), dim3(256), 0, stream, ga, grads[2], tiles_i, 32, WG_TILES);
     return hip_check(hipGetLastError(), "transr launch");
 }
 
