@@ -217,7 +217,7 @@ def main():
                        "optimizer": "Adam(dense, TF1 parity)", "gradient_path": "int8 sign-count records (exact)",
                        "work_threads": WORK_THREADS,
                        "parallelism": "dp%d" % world, "final_loss": loss},
-            "roofline": {"bound": "hbm", "kernel": "kge::transe_emit_vec_kernel<64,1,4,1>",
+            "roofline": {"bound": "hbm", "kernel": "kge::transe_emit_vec_kernel<64,1,4,1,true>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
