@@ -422,3 +422,40 @@ def test_predict_matches_oracle(model):
     got = con.test_step(h, t, r)
     want = orc.predict(h, t, r)
     assert np.allclose(got, want, rtol=1e-5, atol=0)
+
+
+def test_count_image_invariants_at_bench_size(fb_dir):
+    """BASELINE configs[1] at the bench's full size (B = 34 014 positives x 25 negatives, dim 200): properties that
+    need no oracle.  Each scored triple adds +g to its head row and -g to its tail row, so the integer count image
+    sums to zero over the ENTITY rows, column by column; the count of a relation row is bounded by its records; the
+    step is reproducible bit for bit; and the sampled batch keeps the reference's layout (negative k of positive b at
+    B(k+1)+b shares the relation and exactly one entity with it)."""
+    import torch
+    from openkeonspark_amd.Config import Config
+    from openkeonspark_amd.TransE import TransE
+    images, batches = [], []
+    for _ in range(2):
+        con = Config()
+        con.set_in_path(fb_dir); con.set_work_threads(8); con.set_bern(1); con.set_dimension(200); con.set_nbatches(8)
+        con.set_ent_neg_rate(25); con.set_alpha(0.001); con.set_opt_method("Adam")
+        con.init()
+        seeds = np.array(oracle.libc_rand_sequence(8), dtype=np.uint64)
+        con.lib.kge_set_stream_states(seeds.ctypes.data, 8)
+        con.set_model_and_session(TransE)
+        B, n = con.batch_size, 25
+        assert B == 34014
+        dev, n_pos = con.sample_device()
+        con.forward_counts(dev, n_pos, B, B * n, sampler_shaped=True)
+        images.append(con._counts.clone())
+        batches.append(dev.clone())
+        loss = float(con._loss.item())
+        assert 0.5 < loss < 1.5
+    img, bat = images[0], batches[0]
+    assert torch.equal(images[0], images[1]) and torch.equal(batches[0], batches[1])
+    E = con.entTotal
+    assert int(img[:E].sum(dim=0).abs().max()) == 0
+    assert int(img[E:].abs().sum()) > 0 and int(img.abs().max()) <= B * (1 + n)
+    h, t, r = bat[0].view(1 + n, B), bat[1].view(1 + n, B), bat[2].view(1 + n, B)
+    assert bool((r[1:] == r[:1]).all())
+    same_h, same_t = h[1:] == h[:1], t[1:] == t[:1]
+    assert bool((same_h ^ same_t).all())          # exactly one side corrupted, and never to the same entity

@@ -101,3 +101,39 @@ def test_sparse_rejects_unshaped_host_batch():
     br = np.concatenate([r, r])
     with pytest.raises(ok.KgeError):
         con.train_step(bh, bt, br, None)
+
+
+def test_sparse_large_table_properties():
+    """Config #5's regime scaled to fit a test (2 M entities x 512 = 4 GB table, initialised in HBM): size-independent
+    properties of one sparse step.  Every scored triple adds +g to its head row and -g to its tail row, so the integer
+    counts over the ENTITY rows sum to zero column by column; the row list is strictly increasing; only listed rows move."""
+    import torch
+    import openkeonspark_amd as ok
+    E, R, D, n_tr = 2_000_000, 500, 512, 400_000
+    rng = np.random.default_rng(9)
+    h = rng.integers(0, E, n_tr); t = rng.integers(0, E, n_tr); r = rng.integers(0, R, n_tr)
+    con = ok.Config()
+    con.set_work_threads(8); con.set_bern(1); con.set_dimension(D); con.set_ent_neg_rate(2); con.set_rel_neg_rate(0)
+    con.set_alpha(0.01); con.set_opt_method("SGD"); con.set_nbatches(8)        # B = 50 000
+    con.sparse_rows = True
+    con.init_from_arrays(E, R, h, t, r)
+    con.set_model_and_session(ok.TransE)
+    assert con._grads == [] and not hasattr(con, "_counts")                     # no dense image of any kind
+    ent = con._tables[0]
+    assert ent.shape == (E, D) and abs(float(ent[:1000].std()) - np.sqrt(2.6 / (E + D)) * 0.88) < 2e-5
+    probe = torch.arange(0, E, 997, device=ent.device)
+    before = ent[probe].clone()
+    loss = con.train_step()
+    assert 0.5 < loss < 1.5
+    rows, counts = con.sparse_row_gradients()
+    rows_h = rows.cpu().numpy()
+    assert np.all(np.diff(rows_h) > 0) and rows_h.min() >= 0 and rows_h.max() < E + R
+    is_ent = rows < E
+    assert int(counts[is_ent].sum(dim=0).abs().max()) == 0                     # head/tail contributions cancel exactly
+    assert int(counts[~is_ent].abs().sum()) > 0
+    assert int(counts.abs().max()) <= con.batch_size * 3                        # bounded by the records of a hub relation
+    touched = torch.zeros(E, dtype=torch.bool, device=ent.device)
+    touched[rows[is_ent].long()] = True
+    moved = (ent[probe] != before).any(dim=1)
+    assert not bool((moved & ~touched[probe]).any())                            # untouched rows are bit-identical
+    assert bool(moved.any()) or not bool(touched[probe].any())
