@@ -28,8 +28,10 @@ struct SamplerArgs {
     long long n_local;     // positions written by this launch
     long long out_stride;
     long long train_dup, new_batch;
+    unsigned long long pick_div, pick_magic;   // divisor of the positive pick and floor((2^64-1)/divisor)
     int ent_total, rel_total;
     int neg, negrel, bern;
+    int kshift;            // log2 of the lane slots per positive
 };
 
 __device__ __forceinline__ uint64_t lcg_step(uint64_t s) { return s * kLcgMul + kLcgAdd; }
@@ -38,6 +40,33 @@ __device__ __forceinline__ uint64_t lcg_skip(uint64_t s, uint64_t n) {
     for (int j = 0; n != 0; ++j, n >>= 1)
         if (n & 1) s = c_jump.mulA[j] * s + c_jump.addC[j];
     return s;
+}
+
+// s % d for a 64-bit LCG state, exact, without the 64-bit division sequence (~100 instructions each, three per thread):
+// d known on the host -> multiply-high by m = floor((2^64-1)/d), at most two corrections
+__device__ __forceinline__ uint64_t mod_magic(uint64_t s, uint64_t d, uint64_t m) {
+    uint64_t r = s - __umul64hi(s, m) * d;
+    while (r >= d) r -= d;
+    return r;
+}
+// d < 2^31 known only per thread: two rounds of fp64 reciprocal division; each quotient is < 2^32, so the fp64
+// estimate is within one of the truth and one correction step each makes it exact
+__device__ __forceinline__ uint32_t mod_u64_u32(uint64_t s, uint32_t d) {
+    const double rcp = 1.0 / (double)d;
+    const uint32_t hi = (uint32_t)(s >> 32), lo = (uint32_t)s;
+    uint32_t q1 = (uint32_t)((double)hi * rcp);
+    int64_t r1 = (int64_t)hi - (int64_t)q1 * d;
+    if (r1 < 0) r1 += d;
+    if (r1 >= (int64_t)d) r1 -= d;
+    const uint64_t x = ((uint64_t)r1 << 32) | lo;                  // < d * 2^32
+    const double xd = (double)(uint32_t)r1 * 4294967296.0 + (double)lo;
+    uint64_t q2 = (uint64_t)(xd * rcp);
+    int64_t r2 = (int64_t)(x - q2 * d);
+    if (r2 < 0) r2 += d;
+    if (r2 < 0) r2 += d;
+    if (r2 >= (int64_t)d) r2 -= d;
+    if (r2 >= (int64_t)d) r2 -= d;
+    return (uint32_t)r2;
 }
 
 // Corrupt.h:25-36 in closed form: the tmp-th id (0-based) that is NOT in the strictly increasing
@@ -52,20 +81,21 @@ __device__ __forceinline__ int filtered_pick(const int32_t *__restrict__ vals, i
 }
 
 __global__ __launch_bounds__(256) void sample_kernel(SamplerArgs a) {
-    const long long per_pos = 1 + a.neg + a.negrel;
-    const long long total = a.n_local * per_pos;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const long long k = idx / a.n_local;          // 0 = positive, 1..neg entity negatives, then relation negatives
-        const long long b = idx - k * a.n_local;      // local batch position
+    // The 1+neg+negrel draws of one positive sit in ADJACENT lanes (k = 0 positive, 1..neg entity negatives, then
+    // relation negatives; padded to a power of two <= 64): they all read the same pos / grp record and search the same
+    // groups, so those loads coalesce into one request instead of 1+neg requests from as many different blocks.
+    const int kshift = a.kshift, kp = 1 + a.neg + a.negrel;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; (g >> kshift) < a.n_local; g += (long long)gridDim.x * blockDim.x) {
+        const long long b = g >> kshift;
+        const long long k = g & ((1 << kshift) - 1);
+        if (k >= kp) continue;
         const long long p = a.pos_lo + b;             // global batch position
-        const long long id = p / a.per_thread;        // owning virtual thread (Base.cpp:85-92)
+        const long long id = (long long)((unsigned)p / (unsigned)a.per_thread);   // owning virtual thread (Base.cpp:85-92); B < 2^31
         const long long off = p - id * a.per_thread;  // index inside its slice
         const unsigned long long draws = 1ull + 2ull * a.neg + a.negrel;
         uint64_t s = lcg_skip(a.streams[id], (unsigned long long)off * draws);
         s = lcg_step(s);  // Base.cpp:101-106: which training triple
-        long long i = a.new_batch > 0 ? (long long)(s % (unsigned long long)a.new_batch) + (a.train_dup - a.new_batch)
-                                      : (long long)(s % (unsigned long long)a.train_dup);
+        long long i = (long long)mod_magic(s, a.pick_div, a.pick_magic) + (a.new_batch > 0 ? a.train_dup - a.new_batch : 0);
         const int4 tr = a.pos[i];  // (h, t, r, -)
         int oh = tr.x, ot = tr.y, orr = tr.z;
         if (k >= 1 && k <= a.neg) {
@@ -76,17 +106,17 @@ __global__ __launch_bounds__(256) void sample_kernel(SamplerArgs a) {
             s = lcg_step(s);  // Corrupt.h:25: the one draw of the corruption
             const int4 g = a.grp[i];
             if (keep_head) {  // corrupt_head(h, r): new TAIL outside tails(h,r)
-                long long tmp = (long long)(s % (unsigned long long)(a.ent_total - g.y));
+                long long tmp = (long long)mod_u64_u32(s, (uint32_t)(a.ent_total - g.y));
                 ot = filtered_pick(a.tails_hr + g.x, g.y, tmp);
             } else {          // corrupt_tail(t, r): new HEAD outside heads(t,r)
-                long long tmp = (long long)(s % (unsigned long long)(a.ent_total - g.w));
+                long long tmp = (long long)mod_u64_u32(s, (uint32_t)(a.ent_total - g.w));
                 oh = filtered_pick(a.heads_tr + g.z, g.w, tmp);
             }
         } else if (k > a.neg) {  // Base.cpp:133-139: corrupt_rel(h, t)
             s = lcg_skip(s, 2ull * a.neg + (unsigned long long)(k - 1 - a.neg));
             s = lcg_step(s);
             const int2 g = a.ht[i];
-            long long tmp = (long long)(s % (unsigned long long)(a.rel_total - g.y));
+            long long tmp = (long long)mod_u64_u32(s, (uint32_t)(a.rel_total - g.y));
             orr = filtered_pick(a.rels_ht + g.x, g.y, tmp);
         }
         const long long o = b + k * a.out_stride;
@@ -148,9 +178,13 @@ int launch_sampler(int32_t *d_h, int32_t *d_t, int32_t *d_r, int64_t B, int64_t 
         a.train_dup = e.index.train_dup; a.new_batch = e.index.new_batch;
         a.ent_total = (int)e.index.ent_total; a.rel_total = (int)e.index.rel_total;
         a.neg = (int)neg; a.negrel = (int)negrel; a.bern = e.bern ? 1 : 0;
-        const int64_t total = n_local * (1 + neg + negrel);
-        int64_t blocks = (total + 255) / 256;
-        if (blocks > 8192) blocks = 8192;
+        a.pick_div = (unsigned long long)(a.new_batch > 0 ? a.new_batch : a.train_dup);
+        a.pick_magic = ~0ull / a.pick_div;
+        int kshift = 0;
+        while ((1 << kshift) < 1 + neg + negrel) kshift++;
+        a.kshift = kshift;
+        int64_t blocks = ((n_local << kshift) + 255) / 256;
+        if (blocks > (1 << 20)) blocks = 1 << 20;
         hipLaunchKernelGGL(sample_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     }
     hipLaunchKernelGGL(advance_streams_kernel, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, stream, e.dev.streams,
