@@ -117,6 +117,11 @@ const char *kge_version(void);
  *   "float_records_min": smallest number of gradient rows per step that takes the record path (default 65536: measured cross-over, tools/sweep_paths.py)
  *   "index_device_min":  training sets with at least this many lines are indexed on the device (rocPRIM sorts,
  *                        same arrays bit for bit); default 4194304, 0 = always, negative = never
+ *   "hub_copies":        1 (default) = on the fp32-atomic TransH/TransD path, relation-side gradient rows that would
+ *                        take >= 128 adds per step are accumulated in up to 64 copies and folded (same-address
+ *                        atomics serialise); 0 = straight into the accumulators
+ *   "transr_v1":         1 = TransR always on the 32x32x2 MFMA tiles, 2 = 16x16x4 tiles with the all-output-tiles
+ *                        wgrad forced (test hooks; default 0 = automatic)
  *   "time_emit":         1 = bracket the TransE emit kernel with HIP events on its launch stream
  *   "libc_rand_restart": restart the glibc-compatible seed generator, as in a fresh process (the next
  *                        randReset then yields 1804289383, 846930886, ... again) */

@@ -58,6 +58,9 @@ struct FbArgs {
     int32_t *fdst;
     long long hub_base;   // first row of copy 0
     int hub_k, hub_rows;  // copies, rows per copy (R or 2R)
+    // atomic path on a KG with few relations (WN18RR: 11): thousands of groups per step add into the same R rows and
+    // same-address atomics serialise; group b adds into copy b % hub_k of [hub_k][R][D] buffers, folded afterwards
+    float *copies_rel, *copies_auxr;
 };
 
 int ensure_loss_buffers();
@@ -225,13 +228,16 @@ __device__ __forceinline__ void ctx_backward(const Team<L, C> &tm, const FbArgs 
     // hub = first virtual row of this group's copy of the relation-side rows
     float g[C];
     tm.normalize_bwd(cx.rn, Gr, cx.inv_r, cx.uc_r, g);
-    put_row<REC>(tm, a, a.g_rel, r, hub + r, m, g);
+    // atomic path with hub copies: `hub` is the copy index
+    float *grel = (!REC && a.copies_rel) ? a.copies_rel + hub * (long long)a.rel_total * a.D : a.g_rel;
+    float *gaux = (!REC && a.copies_auxr) ? a.copies_auxr + hub * (long long)a.rel_total * a.D : a.g_auxr;
+    put_row<REC>(tm, a, grel, r, hub + r, m, g);
     const long long m2 = m >= 0 ? m + a.n_pos : -1;
     if constexpr (MODEL == KGE_TRANSH) {
         tm.normalize_bwd(cx.cw, acw, cx.inv_w, cx.uc_w, g);
-        put_row<REC>(tm, a, a.g_auxr, r, hub + a.rel_total + r, m2, g);
+        put_row<REC>(tm, a, gaux, r, hub + a.rel_total + r, m2, g);
     } else if constexpr (MODEL == KGE_TRANSD) {
-        put_row<REC>(tm, a, a.g_auxr, r, hub + a.rel_total + r, m2, acw);
+        put_row<REC>(tm, a, gaux, r, hub + a.rel_total + r, m2, acw);
     }
 }
 
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
     for (long long gi = (long long)blockIdx.x * TEAMS + team_in_block; gi < n_groups; gi += (long long)gridDim.x * TEAMS) {
         const long long b = a.group_list ? (long long)a.group_list[gi] : gi;
         const long long h = a.bh[b], t = a.bt[b], r = a.br[b];
-        const long long hub = REC ? a.hub_base + (long long)(b % a.hub_k) * a.hub_rows : 0;
+        const long long hub = REC ? a.hub_base + (long long)(b % a.hub_k) * a.hub_rows : (a.copies_rel ? b % a.hub_k : 0);
         Ctx<C> cx;
         ctx_forward<MODEL, L, C>(tm, a, r, cx);
         // row handles of the two entity sides: the entity id, or (TransR) the slot of the projected
@@ -1038,6 +1044,23 @@ static int dispatch_fb_records(const FbArgs &a, float *d_loss, hipStream_t strea
     return KGE_OK;
 }
 
+// sum the hub copies into the accumulators and re-zero them
+__global__ __launch_bounds__(256) void hub_fold_kernel(float *__restrict__ copies_rel, float *__restrict__ copies_auxr,
+                                                       float *__restrict__ g_rel, float *__restrict__ g_auxr, int K, long long RD) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * RD; i += (long long)gridDim.x * blockDim.x) {
+        float *c = i < RD ? copies_rel : copies_auxr;
+        float *g = i < RD ? g_rel : g_auxr;
+        if (!c) continue;
+        const long long j = i < RD ? i : i - RD;
+        float s = 0.f;
+        for (int k = 0; k < K; k++) {
+            const float v = c[k * RD + j];
+            if (v != 0.f) { s += v; c[k * RD + j] = 0.f; }
+        }
+        if (s != 0.f) g[j] += s;
+    }
+}
+
 template <int MODEL>
 static int dispatch_fb(const FbArgs &a, float *d_loss, hipStream_t stream) {
     const int D = a.D;
@@ -1128,11 +1151,44 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
         rs.E = m.ent_total; rs.R = m.rel_total; rs.hub_base = ent_rows; rs.hub_rows = hub_rows; rs.rows = rows;
         return float_records_reduce(M, a.D, rs, stream);
     }
+    // atomic path: hub copies for the relation-side rows when a row would take hundreds of adds per step
+    const int64_t per_row = hub_rows > 0 ? (group_rel * n_pos) / hub_rows : 0;
+    int64_t copies = 0;
+    if (m.model != KGE_TRANSE && per_row >= 128 && e.hub_copies) {
+        copies = per_row / 16;
+        if (copies > 64) copies = 64;
+        const int64_t per_copy = m.rel_total * (int64_t)a.D;
+        while (copies > 1 && copies * per_copy * 4 > (int64_t(32) << 20)) copies >>= 1;
+        if (copies > 1) {
+            static float *buf_rel = nullptr, *buf_auxr = nullptr;
+            static int64_t buf_elems = 0;
+            if (copies * per_copy > buf_elems) {
+                if (buf_rel) (void)hipFree(buf_rel);
+                if (buf_auxr) (void)hipFree(buf_auxr);
+                buf_rel = buf_auxr = nullptr;
+                buf_elems = copies * per_copy;
+                if ((rc = hip_check(hipMalloc(&buf_rel, sizeof(float) * (size_t)buf_elems), "alloc hub copies"))) return rc;
+                if ((rc = hip_check(hipMalloc(&buf_auxr, sizeof(float) * (size_t)buf_elems), "alloc hub copies"))) return rc;
+                if ((rc = hip_check(hipMemset(buf_rel, 0, sizeof(float) * (size_t)buf_elems), "zero hub copies"))) return rc;
+                if ((rc = hip_check(hipMemset(buf_auxr, 0, sizeof(float) * (size_t)buf_elems), "zero hub copies"))) return rc;
+            }
+            a.copies_rel = buf_rel; a.copies_auxr = buf_auxr; a.hub_k = (int)copies;
+            a.rel_total = (int)m.rel_total;
+        }
+    }
     switch (m.model) {
         case KGE_TRANSE: rc = dispatch_fb<KGE_TRANSE>(a, d_loss, stream); break;
         case KGE_TRANSH: rc = dispatch_fb<KGE_TRANSH>(a, d_loss, stream); break;
         case KGE_TRANSD: rc = dispatch_fb<KGE_TRANSD>(a, d_loss, stream); break;
         default: return fail(KGE_ERR_BAD_ARG, "unknown model id");
+    }
+    if (rc) return rc;
+    if (a.copies_rel) {
+        const long long RD = (long long)m.rel_total * a.D;
+        long long nb = (2 * RD + 255) / 256;
+        if (nb > 1024) nb = 1024;
+        hipLaunchKernelGGL(hub_fold_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.copies_rel, a.copies_auxr, grads[1], grads[2],
+                           a.hub_k, RD);
     }
     if (rc) return rc;
     return hip_check(hipGetLastError(), "forward_backward launch");

@@ -459,3 +459,38 @@ def test_count_image_invariants_at_bench_size(fb_dir):
     assert bool((r[1:] == r[:1]).all())
     same_h, same_t = h[1:] == h[:1], t[1:] == t[:1]
     assert bool((same_h ^ same_t).all())          # exactly one side corrupted, and never to the same entity
+
+
+@pytest.mark.parametrize("model", ["transh", "transd"])
+@pytest.mark.parametrize("copies", [1, 0])
+def test_atomic_path_hub_copies_match_oracle(model, copies):
+    """Few relations, many groups per step: the atomic path spreads the relation-side rows over copies and folds them
+    (same-address atomics serialise).  Same gradients as the oracle either way; accumulators end re-zeroed."""
+    import torch
+    from openkeonspark_amd import _lib
+    L = _lib.lib()
+    E, R, D, B, n = 400, 2, 72, 1500, 2
+    rng = np.random.default_rng(seed_of(model, "hub"))
+    params = oracle.init_params(oracle.MODEL_IDS[model], E, R, D, D, seed=6)
+    for k in params:
+        params[k] = (params[k] * 3).astype(np.float32)
+    orc = oracle.Model(model, E, R, D, D, margin=0.9, params=params)
+    bh, bt, br = batch_without_ties(orc, lambda: rand_batch(rng, E, R, B, n, 0, 0.05), B, n)
+    loss_o, g_o = orc.grad(bh, bt, br, B, n)
+    L.kge_set_option(b"float_records", 0)
+    L.kge_set_option(b"hub_copies", copies)
+    try:
+        con = make_engine(model, E, R, D, n, 0, margin=0.9, params=params)
+        dev = torch.from_numpy(np.stack([bh, bt, br]).astype(np.int32)).cuda()
+        for _ in range(2):                       # twice: the copies must come back zeroed
+            for g in con._grads:
+                g.zero_()
+            con.forward_backward(dev, B, B, B * n)
+            torch.cuda.synchronize()
+            g_g = con.get_gradients()
+            assert abs(float(con._loss.item()) - loss_o) <= RTOL * abs(loss_o)
+            for k in g_o:
+                assert relerr(g_g[k], g_o[k]) < RTOL, (k, relerr(g_g[k], g_o[k]))
+    finally:
+        L.kge_set_option(b"float_records", 1)
+        L.kge_set_option(b"hub_copies", 1)
