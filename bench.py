@@ -104,6 +104,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs a torchrun launch with that many ranks" % args.gpus)
         args.gpus = world
+    if os.environ.get("KGE_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0   # rehearsal of the N-rank code path on a one-GPU box (with KGE_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     # KGE_BENCH_FORCE_DIST=1 exercises the RCCL code path (process group, int32 all-reduce) with a single rank
     use_dist = world > 1 or os.environ.get("KGE_BENCH_FORCE_DIST") == "1"
@@ -112,7 +114,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("KGE_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only for one-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from openkeonspark_amd.synthetic import make_dataset, FB15K237
     from openkeonspark_amd import Config, TransE
