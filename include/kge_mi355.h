@@ -258,6 +258,13 @@ int kge_transe_reduce_records(const kge_model_desc *m, const uint32_t *d_rec, in
                               int32_t *d_row_counts, int32_t *d_n_rows, void *stream);
 int kge_transe_apply_rows_sgd(const kge_model_desc *m, float *d_ent, float *d_rel, const int32_t *d_rows, const int32_t *d_row_counts,
                               const int32_t *d_n_rows, INT max_rows, INT denom, float lr, void *stream);
+/* reduce + apply in one pass (embedding width a multiple of 4): rows whose records all fall inside one 64-record chunk
+ * of the sorted list are updated straight from the registers that hold their sum; only chunk-boundary rows go through
+ * d_row_counts and a second, small pass.  Same bits as kge_transe_reduce_records + kge_transe_apply_rows_sgd.
+ * d_rows / *d_n_rows as there; d_row_counts is only meaningful for the boundary rows afterwards. */
+int kge_transe_reduce_apply_records_sgd(const kge_model_desc *m, const uint32_t *d_rec, int32_t *d_dst, INT n_records, float *d_ent,
+                                        float *d_rel, int32_t *d_rows, int32_t *d_row_counts, int32_t *d_n_rows, INT denom, float lr,
+                                        void *stream);
 
 /* Device-native link prediction for test triples [first, first+count) (replaces the loop
  * distribute_training.py:465-590: getTailBatch -> sess.run(predict) -> testTail, and the head side when

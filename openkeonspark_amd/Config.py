@@ -488,18 +488,25 @@ class Config(object):
             rec, dst = buf["rec_all"], buf["dst_all"]
         else:
             rec, dst = buf["rec"], buf["dst"]
-        _lib.check(self.lib.kge_transe_reduce_records(
-            ctypes.byref(self._desc), rec.data_ptr(), dst.data_ptr(), dst.numel(), buf["rows"].data_ptr(),
-            buf["row_counts"].data_ptr(), buf["n_rows"].data_ptr(), st), self.lib)
-        _lib.check(self.lib.kge_transe_apply_rows_sgd(
-            ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(), buf["rows"].data_ptr(),
-            buf["row_counts"].data_ptr(), buf["n_rows"].data_ptr(), dst.numel(), denom, float(self.alpha), st),
-            self.lib)
+        if getattr(self, "sparse_fused", True) and D % 4 == 0:
+            # reduce + apply in one pass: only chunk-boundary rows go through the compact count image
+            _lib.check(self.lib.kge_transe_reduce_apply_records_sgd(
+                ctypes.byref(self._desc), rec.data_ptr(), dst.data_ptr(), dst.numel(), self._tables[0].data_ptr(),
+                self._tables[1].data_ptr(), buf["rows"].data_ptr(), buf["row_counts"].data_ptr(), buf["n_rows"].data_ptr(),
+                denom, float(self.alpha), st), self.lib)
+        else:
+            _lib.check(self.lib.kge_transe_reduce_records(
+                ctypes.byref(self._desc), rec.data_ptr(), dst.data_ptr(), dst.numel(), buf["rows"].data_ptr(),
+                buf["row_counts"].data_ptr(), buf["n_rows"].data_ptr(), st), self.lib)
+            _lib.check(self.lib.kge_transe_apply_rows_sgd(
+                ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(), buf["rows"].data_ptr(),
+                buf["row_counts"].data_ptr(), buf["n_rows"].data_ptr(), dst.numel(), denom, float(self.alpha), st),
+                self.lib)
         self.global_step += 1
 
     def sparse_row_gradients(self):
         """(rows int32[n], counts int32[n, D]) of the last sparse step: the touched rows (entity rows first, relation
-        rows offset by entTotal) and their integer sign counts."""
+        rows offset by entTotal) and their integer sign counts (complete only with sparse_fused = False)."""
         n = int(self._sparse_buf["n_rows"].item())
         return self._sparse_buf["rows"][:n], self._sparse_buf["row_counts"][:n]
 

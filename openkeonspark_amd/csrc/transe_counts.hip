@@ -46,8 +46,10 @@ struct CtWork {
     int32_t *pairs = nullptr;                                  // [2*cap] (record id, destination) grouped by bucket
     int64_t cap_hist = 0;
     void *sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0, rec_dwords = 0;
-    int64_t cap_rec = 0;
+    size_t sort_tmp_bytes = 0, rec_elems = 0;
+    int64_t cap_idx = 0;
+    int32_t *bflag = nullptr;
+    int64_t bflag_cap = 0;
 };
 CtWork g_c;
 
@@ -58,12 +60,12 @@ int regrow(T *&p, size_t count, const char *what) {
     return hip_check(hipMalloc(&p, sizeof(T) * (count ? count : 1)), what);
 }
 
+// index workspace for M records (keys, ids, sort scratch) and -- rec_dwords > 0 -- an engine-owned record buffer
+// (callers of the stage-level ABI bring their own records and pass 0)
 int ensure_counts_work(int64_t M, size_t rec_dwords) {
     int rc;
-    if (M > g_c.cap_rec || rec_dwords > g_c.rec_dwords) {
-        int64_t cap = M > g_c.cap_rec ? M : g_c.cap_rec;
-        size_t rd = rec_dwords > g_c.rec_dwords ? rec_dwords : g_c.rec_dwords;
-        if ((rc = regrow(g_c.rec, (size_t)cap * rd, "counts records"))) return rc;
+    if (M > g_c.cap_idx) {
+        const int64_t cap = M;
         if ((rc = regrow(g_c.dst, (size_t)cap, "counts dst"))) return rc;
         if ((rc = regrow(g_c.dst_sorted, (size_t)cap, "counts dst_sorted"))) return rc;
         if ((rc = regrow(g_c.ids, (size_t)cap, "counts ids"))) return rc;
@@ -82,7 +84,11 @@ int ensure_counts_work(int64_t M, size_t rec_dwords) {
         std::vector<int32_t> iota((size_t)cap);
         for (int64_t i = 0; i < cap; i++) iota[(size_t)i] = (int32_t)i;
         if ((rc = hip_check(hipMemcpy(g_c.ids, iota.data(), sizeof(int32_t) * (size_t)cap, hipMemcpyHostToDevice), "counts iota"))) return rc;
-        g_c.cap_rec = cap; g_c.rec_dwords = rd;
+        g_c.cap_idx = cap;
+    }
+    if (rec_dwords > 0 && (size_t)M * rec_dwords > g_c.rec_elems) {
+        if ((rc = regrow(g_c.rec, (size_t)M * rec_dwords, "counts records"))) return rc;
+        g_c.rec_elems = (size_t)M * rec_dwords;
     }
     return KGE_OK;
 }
@@ -121,10 +127,71 @@ __device__ __forceinline__ void flush_run(int32_t *__restrict__ S, int D, int la
     }
 }
 
-template <int L, int C, bool NAT>
+// d/dx of the normalised row applied to the integer sign sum: unit * (1/|x|) * (S - x^ <x^,S>), with every
+// operation individually rounded so that all apply kernels agree bit for bit given the same reduction order
+__device__ __forceinline__ float count_grad(float unit, float inv, float s, float d, float xn) {
+    return __fmul_rn(__fmul_rn(unit, inv), __fsub_rn(s, __fmul_rn(d, xn)));
+}
+
+// Sparse-row SGD on ONE row from its summed integer counts held in the NATURAL layout of the vectorised kernels
+// (accumulator c of lane l = element 4*(l + L*(c/4)) + c%4; D % 4 == 0): the single arithmetic used by the fused
+// segmented-sum-and-apply kernel and by the row-list apply kernel, so a row gets the same bits whichever of them
+// handles it (which one does depends on where chunk boundaries fall, i.e. on the number of ranks).
+template <int L, int C>
+__device__ __forceinline__ void apply_row_nat(const int (&acc)[C], float *__restrict__ p, int D, int lane, float unit, float lr) {
+    constexpr int Q = (C + 3) / 4;
+    float x[4 * Q], sv[4 * Q];
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int e0 = 4 * (lane + L * q);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e0 < D) v = *reinterpret_cast<const float4 *>(p + e0);
+        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            sv[4 * q + j] = (4 * q + j < C) ? (float)acc[(4 * q + j < C) ? 4 * q + j : 0] : 0.f;
+            ss += x[4 * q + j] * x[4 * q + j];
+        }
+    }
+    ss = team_sum<L>(ss);
+    const bool uc = ss >= 1e-12f;
+    const float inv = 1.0f / sqrtf(uc ? ss : 1e-12f);
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4 * Q; c++) d += (x[c] * inv) * sv[c];
+    d = team_sum<L>(d);
+    if (!uc) d = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int e0 = 4 * (lane + L * q);
+        if (e0 < D) {
+            float o[4];
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int c = 4 * q + j;
+                const float g = __fadd_rn(count_grad(unit, inv, sv[c], d, x[c] * inv), 0.f);
+                o[j] = g != 0.f ? __fsub_rn(x[c], __fmul_rn(lr, g)) : x[c];
+                any = any || g != 0.f;
+            }
+            if (any) *reinterpret_cast<float4 *>(p + e0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// fused segmented sum + apply (sparse rows, SGD): rows whose records all lie inside one chunk are updated straight from
+// the registers; only chunk-boundary rows go through the compact image (flagged in bflag) and a second, small pass
+struct FuseArgs {
+    float *ent, *rel;
+    long long E;
+    float unit, lr;
+};
+
+template <int L, int C, bool NAT, bool FUSE = false>
 __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict__ rec, const int32_t *__restrict__ keys,
                                                      const int32_t *__restrict__ ids, const int32_t *__restrict__ n_valid_p,
-                                                     const int32_t *__restrict__ uidx, int32_t *__restrict__ S, int D) {
+                                                     const int32_t *__restrict__ uidx, int32_t *__restrict__ S, int D, FuseArgs fz = FuseArgs()) {
     // uidx == nullptr: S is the dense [rows, D] table and a run lands in row `key`;
     // uidx != nullptr: S is compact, a run lands in row uidx[position of the run] (unique-row index)
     constexpr int TEAMS = 256 / L;
@@ -165,7 +232,12 @@ __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict_
         for (int u = 0; u < U; u++) {
             if (k[u] < 0) break;
             if (k[u] != cur) {
-                flush_run<L, C, NAT>(S, D, lane, cur_row, acc, first_run);
+                if (FUSE && !first_run) {   // an interior run: this team holds the row's whole sum
+                    float *prow = cur < fz.E ? fz.ent + (long long)cur * D : fz.rel + ((long long)cur - fz.E) * D;
+                    apply_row_nat<L, C>(acc, prow, D, lane, fz.unit, fz.lr);
+                } else {
+                    flush_run<L, C, NAT>(S, D, lane, cur_row, acc, first_run);
+                }
 #pragma unroll
                 for (int c = 0; c < C; c++) acc[c] = 0;
                 cur = k[u];
@@ -318,7 +390,9 @@ __global__ void run_flags_kernel(const int32_t *__restrict__ keys, const int32_t
 
 // uidx1 = inclusive scan of the run-start flags: record i belongs to unique row uidx1[i]-1
 __global__ void unique_rows_kernel(const int32_t *__restrict__ keys, const int32_t *__restrict__ n_valid_p, int32_t *__restrict__ uidx1,
-                                   int32_t *__restrict__ rows_out, int32_t *__restrict__ n_rows_out, int32_t *__restrict__ S, int D) {
+                                   int32_t *__restrict__ rows_out, int32_t *__restrict__ n_rows_out, int32_t *__restrict__ S, int D,
+                                   int32_t *__restrict__ bflag) {
+    // bflag (fused path, zeroed beforehand): 1 for the rows that go through the compact image
     const int n = n_valid_p[0];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int u = uidx1[i] - 1;
@@ -326,17 +400,14 @@ __global__ void unique_rows_kernel(const int32_t *__restrict__ keys, const int32
         if (i == 0 || keys[i] != keys[i - 1]) rows_out[u] = keys[i];
         if (i == n - 1) n_rows_out[0] = u + 1;
         // rows that a chunk's first / last run touches are accumulated with atomics: clear them first
-        if ((i % CHUNK) == 0 || (i % CHUNK) == CHUNK - 1 || i == n - 1)
+        if ((i % CHUNK) == 0 || (i % CHUNK) == CHUNK - 1 || i == n - 1) {
             for (int e = 0; e < D; e++) S[(long long)u * D + e] = 0;
+            if (bflag) bflag[u] = 1;
+        }
     }
     if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) n_rows_out[0] = 0;
 }
 
-// d/dx of the normalised row applied to the integer sign sum: unit * (1/|x|) * (S - x^ <x^,S>), with every
-// operation individually rounded so that the dense and the sparse-row apply kernels agree bit for bit
-__device__ __forceinline__ float count_grad(float unit, float inv, float s, float d, float xn) {
-    return __fmul_rn(__fmul_rn(unit, inv), __fsub_rn(s, __fmul_rn(d, xn)));
-}
 
 
 // ---------------------------------------------------------------------------------------------
@@ -470,6 +541,33 @@ int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t 
 }
 
 namespace {
+
+// SGD on listed rows from the compact image, natural layout (D % 4 == 0); bflag != nullptr: only flagged rows
+template <int L, int C>
+__global__ __launch_bounds__(256) void apply_rows_nat_kernel(FuseArgs fz, const int32_t *__restrict__ row_list, const int32_t *__restrict__ S,
+                                                             const int32_t *__restrict__ n_rows_p, const int32_t *__restrict__ bflag, int D) {
+    constexpr int TEAMS = 256 / L;
+    constexpr int Q = (C + 3) / 4;
+    const int lane = threadIdx.x % L;
+    const int n = n_rows_p[0];
+    for (long long i = (long long)blockIdx.x * TEAMS + threadIdx.x / L; i < n; i += (long long)gridDim.x * TEAMS) {
+        if (bflag && !bflag[i]) continue;
+        const long long row = row_list[i];
+        int acc[C];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int e0 = 4 * (lane + L * q);
+            int4 v = make_int4(0, 0, 0, 0);
+            if (e0 < D) v = *reinterpret_cast<const int4 *>(S + i * D + e0);
+            if (4 * q < C) acc[4 * q] = v.x;
+            if (4 * q + 1 < C) acc[4 * q + 1] = v.y;
+            if (4 * q + 2 < C) acc[4 * q + 2] = v.z;
+            if (4 * q + 3 < C) acc[4 * q + 3] = v.w;
+        }
+        float *prow = row < fz.E ? fz.ent + row * D : fz.rel + (row - fz.E) * D;
+        apply_row_nat<L, C>(acc, prow, D, lane, fz.unit, fz.lr);
+    }
+}
 
 // stage 3.  optimizer: 0 = SGD (lr), 1 = Adam (lr = lr_t)
 struct ApplyArgs {
@@ -669,9 +767,8 @@ int kge_transe_deferred_groups(int32_t *n_groups) {
     return transe_deferred_groups(n_groups);
 }
 
-int kge_transe_reduce_records(const kge_model_desc *m, const uint32_t *d_rec, int32_t *d_dst, INT n_records, int32_t *d_rows,
-                              int32_t *d_row_counts, int32_t *d_n_rows, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int reduce_records_impl(const kge_model_desc *m, const uint32_t *d_rec, int32_t *d_dst, INT n_records, int32_t *d_rows,
+                               int32_t *d_row_counts, int32_t *d_n_rows, const FuseArgs *fuse, hipStream_t stream) {
     if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_reduce_records: no usable HIP device");
     if (!m || !d_rec || !d_dst || !d_rows || !d_row_counts || !d_n_rows || n_records < 0 || n_records >= (INT(1) << 31))
         return fail(KGE_ERR_BAD_ARG, "kge_transe_reduce_records: bad arguments");
@@ -679,7 +776,7 @@ int kge_transe_reduce_records(const kge_model_desc *m, const uint32_t *d_rec, in
     int L, C;
     transe_team_shape(m->ent_dim, L, C);
     const int64_t M = n_records;
-    int rc = ensure_counts_work(M, (size_t)L * ((C + 3) / 4));
+    int rc = ensure_counts_work(M, 0);   // the records are the caller's
     if (rc) return rc;
     const int rows = (int)(m->ent_total + m->rel_total);
     const int D = m->ent_dim;
@@ -706,8 +803,34 @@ int kge_transe_reduce_records(const kge_model_desc *m, const uint32_t *d_rec, in
     }
     rc = hip_check(rocprim::inclusive_scan(g_c.sort_tmp, scan_bytes, uidx, uidx, (size_t)M, rocprim::plus<int32_t>(), stream), "run scan");
     if (rc) return rc;
+    int32_t *bflag = nullptr;
+    if (fuse) {
+        if (!nat) return fail(KGE_ERR_UNSUPPORTED, "fused reduce+apply needs an embedding width that is a multiple of 4");
+        if ((int64_t)g_c.bflag_cap < M) {
+            if ((rc = regrow(g_c.bflag, (size_t)M, "boundary flags"))) return rc;
+            g_c.bflag_cap = M;
+        }
+        bflag = g_c.bflag;
+        if ((rc = hip_check(hipMemsetAsync(bflag, 0, sizeof(int32_t) * (size_t)M, stream), "zero boundary flags"))) return rc;
+    }
     hipLaunchKernelGGL(unique_rows_kernel, dim3(blocks), dim3(256), 0, stream, g_c.dst_sorted, g_c.n_valid, uidx, d_rows, d_n_rows,
-                       d_row_counts, D);
+                       d_row_counts, D, bflag);
+    if (fuse) {
+#define KGE_SEGFUSE(LL, CC)                                                                                           \
+    {                                                                                                                 \
+        const long long chunks = (M + CHUNK - 1) / CHUNK;                                                             \
+        const long long nb = (chunks + (256 / LL) - 1) / (256 / LL);                                                  \
+        hipLaunchKernelGGL((segsum_kernel<LL, CC, true, true>), dim3((unsigned)nb), dim3(256), 0, stream, d_rec,      \
+                           g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, uidx, d_row_counts, D, *fuse);                \
+        long long nb2 = (M + (256 / LL) - 1) / (256 / LL);                                                            \
+        if (nb2 > 8192) nb2 = 8192;                                                                                   \
+        hipLaunchKernelGGL((apply_rows_nat_kernel<LL, CC>), dim3((unsigned)nb2), dim3(256), 0, stream, *fuse, d_rows,  \
+                           d_row_counts, d_n_rows, bflag, D);                                                         \
+    }
+        KGE_SHAPE_DISPATCH(D, KGE_SEGFUSE)
+#undef KGE_SEGFUSE
+        return hip_check(hipGetLastError(), "records reduce+apply launch");
+    }
 #define KGE_SEGC(LL, CC)                                                                                              \
     {                                                                                                                 \
         const long long chunks = (M + CHUNK - 1) / CHUNK;                                                             \
@@ -722,16 +845,44 @@ int kge_transe_reduce_records(const kge_model_desc *m, const uint32_t *d_rec, in
     return hip_check(hipGetLastError(), "records reduce launch");
 }
 
+int kge_transe_reduce_records(const kge_model_desc *m, const uint32_t *d_rec, int32_t *d_dst, INT n_records, int32_t *d_rows,
+                              int32_t *d_row_counts, int32_t *d_n_rows, void *stream_) {
+    return reduce_records_impl(m, d_rec, d_dst, n_records, d_rows, d_row_counts, d_n_rows, nullptr, (hipStream_t)stream_);
+}
+
+int kge_transe_reduce_apply_records_sgd(const kge_model_desc *m, const uint32_t *d_rec, int32_t *d_dst, INT n_records, float *d_ent,
+                                        float *d_rel, int32_t *d_rows, int32_t *d_row_counts, int32_t *d_n_rows, INT denom, float lr,
+                                        void *stream_) {
+    if (!m || !d_ent || !d_rel || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_transe_reduce_apply_records_sgd: bad arguments");
+    FuseArgs fz;
+    fz.ent = d_ent; fz.rel = d_rel; fz.E = m->ent_total; fz.unit = 1.0f / (float)denom; fz.lr = lr;
+    return reduce_records_impl(m, d_rec, d_dst, n_records, d_rows, d_row_counts, d_n_rows, &fz, (hipStream_t)stream_);
+}
+
 int kge_transe_apply_rows_sgd(const kge_model_desc *m, float *d_ent, float *d_rel, const int32_t *d_rows, const int32_t *d_row_counts,
                               const int32_t *d_n_rows, INT max_rows, INT denom, float lr, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_apply_rows_sgd: no usable HIP device");
     if (!m || !d_rows || !d_row_counts || !d_n_rows || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_rows_sgd: bad arguments");
     if (max_rows <= 0) return KGE_OK;
+    const int D = m->ent_dim;
+    if (D % 4 == 0) {   // the arithmetic of the fused kernel: a row gets the same bits whichever kernel handles it
+        FuseArgs fz;
+        fz.ent = d_ent; fz.rel = d_rel; fz.E = m->ent_total; fz.unit = 1.0f / (float)denom; fz.lr = lr;
+#define KGE_RNAT(LL, CC)                                                                                          \
+    {                                                                                                             \
+        long long nb = (max_rows + (256 / LL) - 1) / (256 / LL);                                                  \
+        if (nb > 8192) nb = 8192;                                                                                 \
+        hipLaunchKernelGGL((apply_rows_nat_kernel<LL, CC>), dim3((unsigned)nb), dim3(256), 0, stream, fz, d_rows, \
+                           d_row_counts, d_n_rows, (const int32_t *)nullptr, D);                                  \
+    }
+        KGE_SHAPE_DISPATCH(D, KGE_RNAT)
+#undef KGE_RNAT
+        return hip_check(hipGetLastError(), "apply rows launch");
+    }
     ApplyArgs a = {};
     a.p = d_ent; a.p2 = d_rel; a.row_list = d_rows; a.S = const_cast<int32_t *>(d_row_counts); a.n_rows = d_n_rows;
     a.E = m->ent_total; a.D = m->ent_dim; a.unit = 1.0f / (float)denom; a.lr = lr; a.adam = 0;
-    const int D = m->ent_dim;
 #define KGE_RAPPLY(LL, CC)                                                                                  \
     {                                                                                                       \
         long long nb = (max_rows + (256 / LL) - 1) / (256 / LL);                                            \
