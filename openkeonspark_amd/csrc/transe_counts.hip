@@ -400,12 +400,25 @@ __global__ void unique_rows_kernel(const int32_t *__restrict__ keys, const int32
         if (i == 0 || keys[i] != keys[i - 1]) rows_out[u] = keys[i];
         if (i == n - 1) n_rows_out[0] = u + 1;
         // rows that a chunk's first / last run touches are accumulated with atomics: clear them first
-        if ((i % CHUNK) == 0 || (i % CHUNK) == CHUNK - 1 || i == n - 1) {
-            for (int e = 0; e < D; e++) S[(long long)u * D + e] = 0;
-            if (bflag) bflag[u] = 1;
-        }
+        if (bflag && ((i % CHUNK) == 0 || (i % CHUNK) == CHUNK - 1 || i == n - 1)) bflag[u] = 1;
     }
     if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) n_rows_out[0] = 0;
+}
+
+// rows that a chunk's first / last run touches are accumulated with atomics: clear them first (64 lanes per row)
+__global__ __launch_bounds__(256) void zero_boundary_rows_kernel(const int32_t *__restrict__ uidx, const int32_t *__restrict__ n_valid_p,
+                                                                 int32_t *__restrict__ S, int D) {
+    const int n = n_valid_p[0];
+    const int lane = threadIdx.x & 63;
+    const long long n_chunks = ((long long)n + CHUNK - 1) / CHUNK;
+    for (long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); c < n_chunks; c += (long long)gridDim.x * 4) {
+        const long long first = c * CHUNK, last = min(first + CHUNK, (long long)n) - 1;
+        const int u0 = uidx[first], u1 = uidx[last];
+        for (int e = lane; e < D; e += 64) {
+            S[(long long)u0 * D + e] = 0;
+            S[(long long)u1 * D + e] = 0;
+        }
+    }
 }
 
 
@@ -815,6 +828,11 @@ static int reduce_records_impl(const kge_model_desc *m, const uint32_t *d_rec, i
     }
     hipLaunchKernelGGL(unique_rows_kernel, dim3(blocks), dim3(256), 0, stream, g_c.dst_sorted, g_c.n_valid, uidx, d_rows, d_n_rows,
                        d_row_counts, D, bflag);
+    {
+        long long zb = ((M + CHUNK - 1) / CHUNK + 3) / 4;
+        if (zb > 8192) zb = 8192;
+        hipLaunchKernelGGL(zero_boundary_rows_kernel, dim3((unsigned)zb), dim3(256), 0, stream, uidx, g_c.n_valid, d_row_counts, D);
+    }
     if (fuse) {
 #define KGE_SEGFUSE(LL, CC)                                                                                           \
     {                                                                                                                 \
