@@ -55,6 +55,7 @@ struct Engine {
     int64_t float_records_min = 1 << 16; // ... from this many gradient rows per step (below it the atomic kernel alone is quicker)
     int64_t index_device_min = int64_t(1) << 22;  // training sets from this many lines on are indexed on the device (index_build.hip); < 0 = never
     int hub_copies = 1;         // atomic TransH/TransD path: spread the relation-side rows over copies when a row takes >= 128 adds per step
+    int lp_v1 = 0;              // test hook: link prediction through the generic predict kernel on materialised candidate batches
     int transr_v1 = 0;          // test hook: 1 = the 32x32x2 / 32-row-tile TransR kernels even where the v2 tiles apply; 2 = v2 with its all-tiles wgrad forced
     int counts_force_sort = 0;  // test hook: take the sort+segsum reduction even for small tables
 };
@@ -112,6 +113,10 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
                             float *const grads[4], float *d_loss, hipStream_t stream);
 int launch_predict(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
                    const int32_t *d_r, int64_t n, float *d_out, hipStream_t stream);
+int launch_lp_table(const kge_model_desc &m, const float *const tables[4], const float *P_all, int64_t r, float *T, hipStream_t stream);
+int launch_lp_scores(const kge_model_desc &m, const float *const tables[4], const float *T, int64_t r, const int32_t *d_req_fixed,
+                     const int32_t *d_req_head, int64_t n_req, float *d_scores, hipStream_t stream);
+int transr_project_all(const kge_model_desc &m, const float *const tables[4], int64_t r, float *P_out, hipStream_t stream);
 int launch_sgd(float *p, float *g, int64_t n, float lr, hipStream_t stream);
 int launch_sgd_tables(int n_tables, float *const *p, float *const *g, const int64_t *numel, float lr, hipStream_t stream);
 int launch_adam_tables(int n_tables, float *const *p, float *const *m, float *const *v, float *const *g, const int64_t *numel,

@@ -548,8 +548,8 @@ INT *get_TPFP(INT r, REAL *score_pos, REAL *score_neg, REAL *score_pos_test, REA
  * ALL entities as tail (and, if test_head != 0, as head) candidates, then the ranker.  out receives
  * count x 2 x 8 int64: [i][0] = testTail result, [i][1] = testHead result (zeros when test_head == 0),
  * each as the reference's 8-vector (distribute_training.py:465-590 consumes exactly these). */
-int kge_link_prediction(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES], INT first, INT count,
-                        INT test_head, int64_t *out, void *stream_) {
+static int link_prediction_v1(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES], INT first, INT count,
+                              INT test_head, int64_t *out, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     int rc = ensure_eval_device();
     if (rc) return rc;
@@ -589,6 +589,112 @@ int kge_link_prediction(const kge_model_desc *m, const float *const tables[KGE_M
             const INT i = idx[q] - first;
             std::memcpy(out + (i * 2 + hd[q]) * 8, res.data() + (size_t)q * 8, sizeof(int64_t) * 8);
         }
+    }
+    return KGE_OK;
+}
+
+
+// Relation-grouped ranker (models.hip lp_table_kernel / lp_score_kernel): importTestFiles keeps the test triples sorted
+// by (r, h, t) (Triple.h:30-32), so the requests of a range are already grouped by relation.  Per relation: one table
+// of all candidates' projected + normalised vectors, one scoring pass per chunk of requests, the rank kernel; the 8-vectors
+// of all requests come back in ONE copy at the end.
+int kge_link_prediction(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES], INT first, INT count,
+                        INT test_head, int64_t *out, void *stream_) {
+    if (engine().lp_v1) return link_prediction_v1(m, tables, first, count, test_head, out, stream_);
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = ensure_eval_device();
+    if (rc) return rc;
+    if (!m || !tables || !out || first < 0 || count < 0 || first + count > g_eh.test_total) return fail(KGE_ERR_BAD_ARG, "kge_link_prediction: bad range");
+    std::memset(out, 0, sizeof(int64_t) * 16 * (size_t)count);
+    if (count == 0) return KGE_OK;
+    const int64_t E = m->ent_total;
+    const int sides = test_head ? 2 : 1;
+    const int64_t n_req = count * sides;
+    const int D = m->model == KGE_TRANSR ? m->rel_dim : m->ent_dim;
+    // requests in the order (test triple, tail then head)
+    std::vector<int32_t> idx((size_t)n_req), hd((size_t)n_req), fixed((size_t)n_req), rel((size_t)n_req);
+    for (int64_t q = 0; q < n_req; q++) {
+        const int64_t i = first + q / sides;
+        const Int4 &tt = g_eh.test[(size_t)i];   // (h, t, r)
+        idx[(size_t)q] = (int32_t)i;
+        hd[(size_t)q] = (int32_t)(q % sides);
+        fixed[(size_t)q] = hd[(size_t)q] ? tt.y : tt.x;   // head request: the tail stays; tail request: the head stays
+        rel[(size_t)q] = tt.z;
+    }
+    static int32_t *d_req = nullptr;     // [3][cap]: test index, head flag, fixed entity
+    static int64_t req_cap = 0;
+    static float *d_T = nullptr, *d_P = nullptr;
+    static int64_t t_cap = 0, p_cap = 0;
+    if (n_req > req_cap) {
+        if (d_req) (void)hipFree(d_req);
+        d_req = nullptr;
+        if ((rc = hip_check(hipMalloc(&d_req, sizeof(int32_t) * 3 * (size_t)n_req), "alloc lp requests"))) return rc;
+        req_cap = n_req;
+    }
+    if (E * D > t_cap) {
+        if (d_T) (void)hipFree(d_T);
+        d_T = nullptr;
+        if ((rc = hip_check(hipMalloc(&d_T, sizeof(float) * (size_t)(E * D)), "alloc lp table"))) return rc;
+        t_cap = E * D;
+    }
+    if (m->model == KGE_TRANSR && (E + 1) * D > p_cap) {
+        if (d_P) (void)hipFree(d_P);
+        d_P = nullptr;
+        if ((rc = hip_check(hipMalloc(&d_P, sizeof(float) * (size_t)((E + 1) * D)), "alloc lp projections"))) return rc;
+        p_cap = (E + 1) * D;
+    }
+    // scores for a chunk of requests: at most 1 GiB
+    int64_t qmax = (int64_t(1) << 28) / (E > 0 ? E : 1);
+    if (qmax < 1) qmax = 1;
+    if (qmax > 4096) qmax = 4096;
+    if (qmax > n_req) qmax = n_req;
+    if (g_ed.scores_cap < qmax * E) {
+        if (g_ed.scores) (void)hipFree(g_ed.scores);
+        if (g_ed.cand) (void)hipFree(g_ed.cand);
+        g_ed.scores = nullptr; g_ed.cand = nullptr;
+        if ((rc = hip_check(hipMalloc(&g_ed.scores, sizeof(float) * (size_t)(qmax * E)), "alloc scores"))) return rc;
+        g_ed.scores_cap = qmax * E;
+    }
+    if (g_ed.out_cap < n_req) {
+        if (g_ed.out) (void)hipFree(g_ed.out);
+        g_ed.out = nullptr;
+        if ((rc = hip_check(hipMalloc(&g_ed.out, sizeof(long long) * 8 * (size_t)n_req), "alloc rank out"))) return rc;
+        g_ed.out_cap = (int)n_req;
+    }
+    int32_t *d_idx = d_req, *d_hd = d_req + req_cap, *d_fixed = d_req + 2 * req_cap;
+    if ((rc = hip_check(hipMemcpyAsync(d_idx, idx.data(), sizeof(int32_t) * (size_t)n_req, hipMemcpyHostToDevice, stream), "upload req"))) return rc;
+    if ((rc = hip_check(hipMemcpyAsync(d_hd, hd.data(), sizeof(int32_t) * (size_t)n_req, hipMemcpyHostToDevice, stream), "upload req"))) return rc;
+    if ((rc = hip_check(hipMemcpyAsync(d_fixed, fixed.data(), sizeof(int32_t) * (size_t)n_req, hipMemcpyHostToDevice, stream), "upload req"))) return rc;
+    RankArgs a;
+    a.test = g_ed.test; a.all = g_ed.all; a.n_all = (long long)g_eh.all.size();
+    a.head_lef = g_ed.head_lef; a.head_rig = g_ed.head_rig; a.tail_lef = g_ed.tail_lef; a.tail_rig = g_ed.tail_rig;
+    a.head_type = g_ed.head_type; a.tail_type = g_ed.tail_type;
+    a.sup_lef = g_ed.sup_lef; a.sup_rig = g_ed.sup_rig; a.sub_lef = g_ed.sub_lef; a.sub_rig = g_ed.sub_rig;
+    a.sup_type = g_ed.sup_type; a.sub_type = g_ed.sub_type; a.E = (int)E;
+    bool have_table = false;
+    for (int64_t q0 = 0; q0 < n_req;) {
+        const int32_t r = rel[(size_t)q0];
+        int64_t q1 = q0;
+        while (q1 < n_req && rel[(size_t)q1] == r) q1++;
+        if (m->model != KGE_TRANSE || !have_table) {   // TransE's candidates do not depend on the relation
+            if (m->model == KGE_TRANSR && (rc = transr_project_all(*m, tables, r, d_P, stream))) return rc;
+            if ((rc = launch_lp_table(*m, tables, d_P, r, d_T, stream))) return rc;
+            have_table = true;
+        }
+        for (int64_t c0 = q0; c0 < q1; c0 += qmax) {
+            const int64_t n = std::min<int64_t>(qmax, q1 - c0);
+            if ((rc = launch_lp_scores(*m, tables, d_T, r, d_fixed + c0, d_hd + c0, n, g_ed.scores, stream))) return rc;
+            a.scores = g_ed.scores; a.req_index = d_idx + c0; a.req_head = d_hd + c0; a.out = g_ed.out + c0 * 8;
+            hipLaunchKernelGGL(rank_kernel, dim3((unsigned)n), dim3(256), 0, stream, a);
+        }
+        q0 = q1;
+    }
+    std::vector<long long> res((size_t)n_req * 8);
+    if ((rc = hip_check(hipMemcpyAsync(res.data(), g_ed.out, sizeof(long long) * 8 * (size_t)n_req, hipMemcpyDeviceToHost, stream), "copy ranks"))) return rc;
+    if ((rc = hip_check(hipStreamSynchronize(stream), "rank sync"))) return rc;
+    for (int64_t q = 0; q < n_req; q++) {
+        const int64_t i = q / sides;
+        std::memcpy(out + (i * 2 + hd[(size_t)q]) * 8, res.data() + (size_t)q * 8, sizeof(int64_t) * 8);
     }
     return KGE_OK;
 }

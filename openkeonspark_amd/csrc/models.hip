@@ -1271,4 +1271,109 @@ int launch_predict(const kge_model_desc &m, const float *const tables[4], const 
     return hip_check(hipGetLastError(), "predict launch");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Link prediction, relation-grouped (eval.hip kge_link_prediction): the test triples of one relation r all rank the
+// same E candidates under the same relation context, so the candidates' projected + normalised vectors are built ONCE
+// per relation into a table T_r [E, D] (for TransE: once per call), and a request only streams T_r against its fixed
+// side -- one row read and one reduction per candidate instead of three rows, two projections and three normalisations.
+// The arithmetic is the predict kernel's, function for function (ctx_forward, side_forward, l1_score), so the scores
+// are bit-identical to kge_predict on getHeadBatch / getTailBatch.
+// ------------------------------------------------------------------------------------------------
+template <int MODEL, int L, int C>
+__global__ __launch_bounds__(256) void lp_table_kernel(FbArgs a, long long r, long long E, float *__restrict__ T) {
+    constexpr int TEAMS = 256 / L;
+    Team<L, C> tm;
+    tm.lane = threadIdx.x % L;
+    tm.D = a.D;
+    Ctx<C> cx;
+    ctx_forward<MODEL, L, C>(tm, a, r, cx);
+    for (long long j = (long long)blockIdx.x * TEAMS + threadIdx.x / L; j < E; j += (long long)gridDim.x * TEAMS) {
+        Side<C> s;
+        side_forward<MODEL, L, C>(tm, a, j, cx.cw, s);   // TransR: row j of a.P (all entities projected by M_r)
+        tm.store(T, j, s.nrm);
+    }
+}
+
+template <int MODEL, int L, int C>
+__global__ __launch_bounds__(256) void lp_score_kernel(FbArgs a, const float *__restrict__ T, long long r, const int32_t *__restrict__ req_fixed,
+                                                       const int32_t *__restrict__ req_head, long long E, float *__restrict__ scores) {
+    constexpr int TEAMS = 256 / L;
+    Team<L, C> tm;
+    tm.lane = threadIdx.x % L;
+    tm.D = a.D;
+    const long long q = blockIdx.y;
+    Ctx<C> cx;
+    ctx_forward<MODEL, L, C>(tm, a, r, cx);
+    float fixed[C], x[C], sg[C];
+    tm.load(T, req_fixed[q], fixed);
+    const bool head = req_head[q] != 0;
+    float *out = scores + q * E;
+    for (long long j = (long long)blockIdx.x * TEAMS + threadIdx.x / L; j < E; j += (long long)gridDim.x * TEAMS) {
+        tm.load(T, j, x);
+        const float s = head ? l1_score<L, C>(tm, x, cx.rn, fixed, sg) : l1_score<L, C>(tm, fixed, cx.rn, x, sg);
+        if (tm.lane == 0) out[j] = MODEL == KGE_TRANSE ? s / (float)a.D : s;
+    }
+}
+
+// T_r for every entity.  TransR: P = all entities projected by M_r (transr.hip) must be in `P_all`.
+int launch_lp_table(const kge_model_desc &m, const float *const tables[4], const float *P_all, int64_t r, float *T, hipStream_t stream) {
+    FbArgs a = {};
+    a.ent = tables[0]; a.rel = tables[1]; a.auxr = tables[2]; a.auxe = tables[3]; a.P = P_all;
+    a.D = m.model == KGE_TRANSR ? m.rel_dim : m.ent_dim;
+    const long long E = m.ent_total;
+    const int D = a.D;
+#define KGE_LPT(MODEL, LL, CC)                                                                                         \
+    {                                                                                                                  \
+        long long blocks = (E + (256 / LL) - 1) / (256 / LL);                                                          \
+        if (blocks > 4096) blocks = 4096;                                                                              \
+        hipLaunchKernelGGL((lp_table_kernel<MODEL, LL, CC>), dim3((unsigned)blocks), dim3(256), 0, stream, a, (long long)r, E, T); \
+    }
+#define KGE_LPT_D(MODEL)                                                                                               \
+    if (D <= 16) KGE_LPT(MODEL, 16, 1) else if (D <= 32) KGE_LPT(MODEL, 16, 2) else if (D <= 64) KGE_LPT(MODEL, 16, 4)  \
+    else if (D <= 128) KGE_LPT(MODEL, 32, 4) else if (D <= 256) KGE_LPT(MODEL, 64, 4) else if (D <= 512) KGE_LPT(MODEL, 64, 8) \
+    else if (D <= 1024) KGE_LPT(MODEL, 64, 16) else return fail(KGE_ERR_UNSUPPORTED, "embedding dimension > 1024");
+    switch (m.model) {
+        case KGE_TRANSE: KGE_LPT_D(KGE_TRANSE) break;
+        case KGE_TRANSH: KGE_LPT_D(KGE_TRANSH) break;
+        case KGE_TRANSR: KGE_LPT_D(KGE_TRANSR) break;
+        case KGE_TRANSD: KGE_LPT_D(KGE_TRANSD) break;
+        default: return fail(KGE_ERR_BAD_ARG, "unknown model id");
+    }
+#undef KGE_LPT_D
+#undef KGE_LPT
+    return hip_check(hipGetLastError(), "lp table launch");
+}
+
+int launch_lp_scores(const kge_model_desc &m, const float *const tables[4], const float *T, int64_t r, const int32_t *d_req_fixed,
+                     const int32_t *d_req_head, int64_t n_req, float *d_scores, hipStream_t stream) {
+    if (n_req <= 0) return KGE_OK;
+    FbArgs a = {};
+    a.ent = tables[0]; a.rel = tables[1]; a.auxr = tables[2]; a.auxe = tables[3];
+    a.D = m.model == KGE_TRANSR ? m.rel_dim : m.ent_dim;
+    const long long E = m.ent_total;
+    const int D = a.D;
+#define KGE_LPS(MODEL, LL, CC)                                                                                         \
+    {                                                                                                                  \
+        long long bx = (E + (256 / LL) * 16 - 1) / ((256 / LL) * 16);   /* ~16 candidates per team */                  \
+        if (bx > 1024) bx = 1024;                                                                                      \
+        if (bx < 1) bx = 1;                                                                                            \
+        hipLaunchKernelGGL((lp_score_kernel<MODEL, LL, CC>), dim3((unsigned)bx, (unsigned)n_req), dim3(256), 0, stream, a, T, \
+                           (long long)r, d_req_fixed, d_req_head, E, d_scores);                                        \
+    }
+#define KGE_LPS_D(MODEL)                                                                                               \
+    if (D <= 16) KGE_LPS(MODEL, 16, 1) else if (D <= 32) KGE_LPS(MODEL, 16, 2) else if (D <= 64) KGE_LPS(MODEL, 16, 4)  \
+    else if (D <= 128) KGE_LPS(MODEL, 32, 4) else if (D <= 256) KGE_LPS(MODEL, 64, 4) else if (D <= 512) KGE_LPS(MODEL, 64, 8) \
+    else if (D <= 1024) KGE_LPS(MODEL, 64, 16) else return fail(KGE_ERR_UNSUPPORTED, "embedding dimension > 1024");
+    switch (m.model) {   // only ctx_forward's relation vector and the TransE mean differ between models here
+        case KGE_TRANSE: KGE_LPS_D(KGE_TRANSE) break;
+        case KGE_TRANSH: KGE_LPS_D(KGE_TRANSH) break;
+        case KGE_TRANSR: KGE_LPS_D(KGE_TRANSR) break;
+        case KGE_TRANSD: KGE_LPS_D(KGE_TRANSD) break;
+        default: return fail(KGE_ERR_BAD_ARG, "unknown model id");
+    }
+#undef KGE_LPS_D
+#undef KGE_LPS
+    return hip_check(hipGetLastError(), "lp score launch");
+}
+
 }  // namespace kge

@@ -720,4 +720,39 @@ int launch_predict_transr(const kge_model_desc &m, const float *const tables[4],
     return launch_transr_predict_stage(tables[1], g_w.P, d_r, n, Dr, d_out, stream);
 }
 
+// link prediction: P_out[j] = ent[j] . M_r for EVERY entity j (one relation bucket holding all E rows)
+namespace {
+__global__ void project_all_prep_kernel(long long E, int r0, int R, int32_t *__restrict__ vals, int32_t *__restrict__ job_ent,
+                                        int32_t *__restrict__ bucket_start, int32_t *__restrict__ tile_rel,
+                                        int32_t *__restrict__ tile_row0, int32_t *__restrict__ n_tiles) {
+    for (long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x; slot < E; slot += (long long)gridDim.x * blockDim.x) {
+        vals[slot] = (int32_t)slot;
+        job_ent[slot] = (int32_t)slot;
+        if ((slot & 31) == 0) { tile_rel[slot >> 5] = r0; tile_row0[slot >> 5] = (int32_t)slot; }
+    }
+    if (blockIdx.x == 0) {
+        for (int r = threadIdx.x; r <= R + 1; r += blockDim.x) bucket_start[r] = r <= r0 ? 0 : (int32_t)E;
+        if (threadIdx.x == 0) n_tiles[0] = (int)((E + 31) >> 5);
+    }
+}
+}  // namespace
+
+int transr_project_all(const kge_model_desc &m, const float *const tables[4], int64_t r, float *P_out, hipStream_t stream) {
+    const int De = m.ent_dim, Dr = m.rel_dim;
+    const int64_t R = m.rel_total, E = m.ent_total;
+    int rc = ensure_work(E, Dr, R);
+    if (rc) return rc;
+    int blocks = (int)((E + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(project_all_prep_kernel, dim3(blocks), dim3(256), 0, stream, (long long)E, (int)r, (int)R, g_w.vals2, g_w.job_ent,
+                       g_w.bucket_start, g_w.tile_rel, g_w.tile_row0, g_w.n_tiles);
+    GemmArgs ga = {};
+    ga.ent = tables[0]; ga.mat = tables[2]; ga.P = P_out;
+    ga.sorted_slots = g_w.vals2; ga.job_ent = g_w.job_ent; ga.bucket_start = g_w.bucket_start;
+    ga.tile_rel = g_w.tile_rel; ga.tile_row0 = g_w.tile_row0; ga.n_tiles = g_w.n_tiles;
+    ga.De = De; ga.Dr = Dr;
+    hipLaunchKernelGGL((rows_gemm_kernel<GEMM_PROJECT>), dim3((unsigned)((E + 31) / 32), (Dr + TN - 1) / TN), dim3(256), 0, stream, ga);
+    return hip_check(hipGetLastError(), "transr project-all launch");
+}
+
 }  // namespace kge

@@ -72,3 +72,34 @@ def test_device_link_prediction_matches_oracle(model):
     assert mismatched <= 2
     assert 0.0 <= metrics["r_filter_tot"] <= 1.0 and metrics["r_rank"] >= 1.0 and metrics["l_filter_rank"] >= 1.0
     assert metrics["r_filter_rank"] <= metrics["r_rank"]
+
+
+@pytest.mark.parametrize("model", ["TransE", "TransH", "TransD", "TransR"])
+@pytest.mark.parametrize("test_head", [True, False])
+def test_relation_grouped_ranker_equals_generic_predict_path(model, test_head):
+    """kge_link_prediction builds one table of projected + normalised candidates per relation and streams it against
+    every request of that relation; the older route materialises getHeadBatch / getTailBatch and runs kge_predict.
+    Same functions, same operation order: identical 8-vectors for the WHOLE test set (ragged relation groups,
+    relations with a single test triple, both sides)."""
+    kg = "kg_small"
+    con = make_config(kg, model, dim=40)
+    import torch
+    for t in con._tables:                       # spread the scores: xavier-initialised tables rank almost at random
+        t.mul_(3.0)
+    L = con.lib
+    outs = []
+    for v1 in (1, 0):
+        L.kge_set_option(b"lp_v1", v1)
+        try:
+            out, met = con.link_prediction(test_head=test_head)
+        finally:
+            L.kge_set_option(b"lp_v1", 0)
+        outs.append((out, met))
+    assert outs[0][0].shape[0] == L.getTestTotal()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
+    assert outs[0][0][:, 0, 0].max() > 0
+    # a sub-range starting inside a relation group
+    L.kge_set_option(b"lp_v1", 0)
+    sub, _ = con.link_prediction(first=5, count=17, test_head=test_head)
+    assert np.array_equal(sub, outs[1][0][5:22])
