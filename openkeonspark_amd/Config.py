@@ -551,6 +551,55 @@ class Config(object):
         self.trainModel.predict = out
         return out.cpu().numpy()
 
+    @staticmethod
+    def _lp_sums(out, test_head=True):
+        """Un-normalised accumulators of main_spark.py:430-448 over the rows of `out` (they add across test-set slices)."""
+        d = {}
+        for side, p in ((0, "r"), (1, "l")):
+            if side == 1 and not test_head:
+                continue
+            raw, filt, raw_c, filt_c = (out[:, side, i] for i in range(4))
+            for name, cnt in (("", raw), ("_filter", filt)):
+                d[p + name + "_tot"] = float((cnt < 10).sum())                    # Hits@10
+                d[p + "3" + name + "_tot"] = float((cnt < 3).sum())               # Hits@3
+                d[p + "1" + name + "_tot"] = float((cnt < 1).sum())               # Hits@1
+                d[p + name + "_rank"] = float((1 + cnt).sum())                    # MR
+                d[p + name + "_reci_rank"] = float((1.0 / (1 + cnt)).sum())       # MRR
+            for name, cnt in (("", raw_c), ("_filter", filt_c)):
+                d[p + name + "_tot_constrain"] = float((cnt < 10).sum())
+                d[p + "3" + name + "_tot_constrain"] = float((cnt < 3).sum())
+                d[p + "1" + name + "_tot_constrain"] = float((cnt < 1).sum())
+                d[p + name + "_rank_constrain"] = float((1 + cnt).sum())
+                d[p + name + "_reci_rank_constrain"] = float((1.0 / (1 + cnt)).sum())
+        return d
+
+    @staticmethod
+    def _lp_normalise(sums, count):
+        n = float(max(count, 1))
+        return {k: v / n for k, v in sums.items()}
+
+    def link_prediction_distributed(self, test_head=True):
+        """The whole test set, split into one contiguous range per rank (the static split of
+        distribute_training.py:430-441) and reduced like main_spark.py:430-448: every rank returns the global metrics."""
+        import torch
+        import torch.distributed as dist
+        total = self.lib.getTestTotal()
+        per = (total + self.world_size - 1) // self.world_size
+        lo = min(self.rank * per, total)
+        hi = min(lo + per, total)
+        out = np.zeros((hi - lo, 2, 8), dtype=np.int64)
+        if hi > lo:
+            _lib.check(self.lib.kge_link_prediction(ctypes.byref(self._desc), self._tab_ptrs, lo, hi - lo,
+                                                    1 if test_head else 0, out.ctypes.data, self._stream()), self.lib)
+        sums = self._lp_sums(out, test_head)
+        keys = sorted(sums)
+        vec = torch.tensor([sums[k] for k in keys], dtype=torch.float64)
+        if self.world_size > 1:
+            if dist.get_backend(self._pg) == "nccl":
+                vec = vec.to(self.device)
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self._pg)
+        return self._lp_normalise(dict(zip(keys, vec.cpu().tolist())), total)
+
     def link_prediction(self, first=0, count=None, test_head=True):
         """Rank every test triple in [first, first+count) on the device (replaces the per-triple loop of
         distribute_training.py:465-590).  Returns (raw int64 [count,2,8] as testTail/testHead give them,
@@ -561,25 +610,7 @@ class Config(object):
         out = np.zeros((count, 2, 8), dtype=np.int64)
         _lib.check(self.lib.kge_link_prediction(ctypes.byref(self._desc), self._tab_ptrs, first, count,
                                                 1 if test_head else 0, out.ctypes.data, self._stream()), self.lib)
-        d = {}
-        n = float(max(count, 1))
-        for side, p in ((0, "r"), (1, "l")):
-            if side == 1 and not test_head:
-                continue
-            raw, filt, raw_c, filt_c = (out[:, side, i] for i in range(4))
-            for name, cnt in (("", raw), ("_filter", filt)):
-                sfx = name
-                d[p + sfx + "_tot"] = float((cnt < 10).sum()) / n          # Hits@10
-                d[p + "3" + sfx + "_tot"] = float((cnt < 3).sum()) / n      # Hits@3
-                d[p + "1" + sfx + "_tot"] = float((cnt < 1).sum()) / n      # Hits@1
-                d[p + sfx + "_rank"] = float((1 + cnt).sum()) / n           # MR
-                d[p + sfx + "_reci_rank"] = float((1.0 / (1 + cnt)).sum()) / n  # MRR
-            for name, cnt in (("", raw_c), ("_filter", filt_c)):
-                d[p + name + "_tot_constrain"] = float((cnt < 10).sum()) / n
-                d[p + "3" + name + "_tot_constrain"] = float((cnt < 3).sum()) / n
-                d[p + "1" + name + "_tot_constrain"] = float((cnt < 1).sum()) / n
-                d[p + name + "_rank_constrain"] = float((1 + cnt).sum()) / n
-                d[p + name + "_reci_rank_constrain"] = float((1.0 / (1 + cnt)).sum()) / n
+        d = self._lp_normalise(self._lp_sums(out, test_head), count)
         return out, d
 
     # ------------------------------------------------------------------------------------------

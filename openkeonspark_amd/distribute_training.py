@@ -239,7 +239,10 @@ def main_fun(argv):
         restore_checkpoint(con, os.path.join(argv.output_path, "model.ckpt-%d.npz" % last_global_step))
 
     if argv.mode != "train":
-        out, metrics = con.link_prediction(test_head=bool(argv.test_head))
+        if distributed:   # one contiguous slice of the test set per rank, accumulators all-reduced
+            metrics = con.link_prediction_distributed(test_head=bool(argv.test_head))
+        else:
+            out, metrics = con.link_prediction(test_head=bool(argv.test_head))
         if rank == 0:
             print(json.dumps(metrics, indent=1))
             if argv.output_path:

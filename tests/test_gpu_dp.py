@@ -95,3 +95,52 @@ def test_two_ranks_with_prefetched_sampling(tmp_path):
             continue
         assert np.array_equal(r0[k], r1[k]), k
         assert np.array_equal(r0[k], one[k]), k    # integer counts: bit-identical to the single-process run
+
+
+def _lp_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import json
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import openkeonspark_amd as pkg
+    con = pkg.Config()
+    con.set_in_path(os.path.join(GOLDEN, "kg_small"))
+    con.set_work_threads(2); con.set_dimension(32); con.set_test_link_prediction(True)
+    con.init()
+    torch.manual_seed(0)
+    con.set_model_and_session(pkg.TransH)
+    for t in con._tables:
+        t.mul_(3.0)
+    if world > 1:
+        con.init_distributed()
+    met = con.link_prediction_distributed(test_head=True)
+    if world == 1:
+        _, ref = con.link_prediction(test_head=True)
+        assert ref.keys() == met.keys()
+        for k in ref:
+            assert abs(ref[k] - met[k]) <= 1e-12 * max(1.0, abs(ref[k])), k
+    json.dump(met, open(os.path.join(out_dir, "lp_w%d_r%d.json" % (world, rank)), "w"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_link_prediction_split_over_ranks(tmp_path):
+    """Static range split of the test set over ranks + all-reduced accumulators (distribute_training.py:430-441,
+    main_spark.py:430-448): every rank reports the single-process metrics."""
+    import json
+    import torch.multiprocessing as mp
+    port = 29900 + os.getpid() % 1000
+    mp.start_processes(_lp_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True, start_method="spawn")
+    mp.start_processes(_lp_worker, args=(2, port + 1, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    one = json.load(open(str(tmp_path / "lp_w1_r0.json")))
+    for r in (0, 1):
+        two = json.load(open(str(tmp_path / ("lp_w2_r%d.json" % r))))
+        assert one.keys() == two.keys() and len(one) == 40
+        for k in one:
+            assert abs(one[k] - two[k]) <= 1e-12 * max(1.0, abs(one[k])), k
+    assert one["r_filter_rank"] >= 1.0 and one["l_rank"] >= one["l_filter_rank"]
