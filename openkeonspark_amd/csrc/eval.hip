@@ -29,7 +29,7 @@ struct EvalHost {
 
 struct EvalDev {
     bool uploaded = false;
-    int4 *test = nullptr, *all = nullptr;
+    int4 *test = nullptr, *all = nullptr, *all_t = nullptr;   // all_t: the same triples as (t,r,h,0) sorted by (t,r,h)
     int32_t *head_lef = nullptr, *head_rig = nullptr, *tail_lef = nullptr, *tail_rig = nullptr, *head_type = nullptr, *tail_type = nullptr;
     int32_t *sup_lef = nullptr, *sup_rig = nullptr, *sub_lef = nullptr, *sub_rig = nullptr, *sup_type = nullptr, *sub_type = nullptr;
     float *scores = nullptr;      // staging for testHead/testTail and kge_link_prediction
@@ -66,6 +66,13 @@ static int ensure_eval_device() {
     if (g_eh.sup_lef.empty()) { g_eh.sup_lef.assign(E, 0); g_eh.sup_rig.assign(E, 0); g_eh.sub_lef.assign(E, 0); g_eh.sub_rig.assign(E, 0); }
     if ((rc = up(g_ed.test, g_eh.test, "upload test"))) return rc;
     if ((rc = up(g_ed.all, g_eh.all, "upload triples"))) return rc;
+    {   // second order for head requests: the known heads of a (t, r) pair are then contiguous
+        std::vector<Int4> by_tail(g_eh.all.size());
+        for (size_t i = 0; i < by_tail.size(); i++) by_tail[i] = Int4{g_eh.all[i].z, g_eh.all[i].y, g_eh.all[i].x, 0};
+        std::sort(by_tail.begin(), by_tail.end(), [](const Int4 &a, const Int4 &b) {
+            if (a.x != b.x) return a.x < b.x; if (a.y != b.y) return a.y < b.y; return a.z < b.z; });
+        if ((rc = up(g_ed.all_t, by_tail, "upload triples by tail"))) return rc;
+    }
     if ((rc = up(g_ed.head_lef, g_eh.head_lef, "upload types"))) return rc;
     if ((rc = up(g_ed.head_rig, g_eh.head_rig, "upload types"))) return rc;
     if ((rc = up(g_ed.tail_lef, g_eh.tail_lef, "upload types"))) return rc;
@@ -85,7 +92,7 @@ static int ensure_eval_device() {
 // ---------------------------------------------------------------------------------------------
 struct RankArgs {
     const float *scores;     // [n_req][E]
-    const int4 *test, *all;
+    const int4 *test, *all, *all_t;
     long long n_all;
     const int32_t *head_lef, *head_rig, *tail_lef, *tail_rig, *head_type, *tail_type;
     const int32_t *sup_lef, *sup_rig, *sub_lef, *sub_rig, *sup_type, *sub_type;
@@ -95,16 +102,20 @@ struct RankArgs {
     int E;
 };
 
-// Corrupt.h:104-115
-__device__ __forceinline__ bool known_triple(const int4 *__restrict__ all, long long n, int h, int t, int r) {
-    long long lef = 0, rig = n - 1;
-    while (lef + 1 < rig) {
-        const long long mid = (lef + rig) >> 1;
-        const int4 m = all[mid];  // (h, r, t)
-        if (m.x < h || (m.x == h && m.y < r) || (m.x == h && m.y == r && m.z < t)) lef = mid; else rig = mid;
-    }
-    const int4 a = all[lef], b = all[rig];
-    return (a.x == h && a.y == r && a.z == t) || (b.x == h && b.y == r && b.z == t);
+// [lo, hi) of the entries whose first two fields are (a, b) in an array sorted by (x, y, z): the third fields of that
+// range are the known tails of (h, r) in `all`, or the known heads of (t, r) in `all_t`, in increasing order
+__device__ __forceinline__ void pair_range(const int4 *__restrict__ arr, long long n, int a, int b, long long &lo, long long &hi) {
+    long long l = 0, r = n;
+    while (l < r) { const long long mid = (l + r) >> 1; const int4 m = arr[mid]; if (m.x < a || (m.x == a && m.y < b)) l = mid + 1; else r = mid; }
+    lo = l;
+    r = n;
+    while (l < r) { const long long mid = (l + r) >> 1; const int4 m = arr[mid]; if (m.x < a || (m.x == a && m.y <= b)) l = mid + 1; else r = mid; }
+    hi = l;
+}
+__device__ __forceinline__ bool in_range(const int4 *__restrict__ arr, long long lo, long long hi, int j) {
+    const long long end = hi;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (arr[mid].z < j) lo = mid + 1; else hi = mid; }
+    return lo < end && arr[lo].z == j;
 }
 
 struct MinPair { float v; int j; };
@@ -120,6 +131,17 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
     const float minimal = con[target];
     const int lef = head ? a.head_lef[r] : a.tail_lef[r], rig = head ? a.head_rig[r] : a.tail_rig[r];
     const int32_t *types = head ? a.head_type : a.tail_type;
+    // the filter (Corrupt.h:104-115 `_find` over train+valid+test): the known tails of (h, r) / heads of (t, r) are one
+    // contiguous, sorted range, located once per request; a candidate then costs a search in that short range
+    __shared__ long long s_known[2];
+    if (threadIdx.x == 0) {
+        long long lo, hi;
+        if (head) pair_range(a.all_t, a.n_all, t, r, lo, hi); else pair_range(a.all, a.n_all, h, r, lo, hi);
+        s_known[0] = lo; s_known[1] = hi;
+    }
+    __syncthreads();
+    const long long known_lo = s_known[0], known_hi = s_known[1];
+    const int4 *known_arr = head ? a.all_t : a.all;
     long long c[4] = {0, 0, 0, 0};
     // arg-min candidates start at (minimal, target); a candidate must be STRICTLY lower to replace it
     MinPair m[4];
@@ -128,7 +150,7 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
         if (j == target) continue;
         const float value = con[j];
         if (!(value < minimal)) continue;
-        const bool known = head ? known_triple(a.all, a.n_all, j, t, r) : known_triple(a.all, a.n_all, h, j, r);
+        const bool known = in_range(known_arr, known_lo, known_hi, j);
         bool typed = false;
         {   // lower_bound in the relation's sorted type list
             int lo = lef, hi = rig;
@@ -205,7 +227,7 @@ static int rank_requests(const float *d_scores, const std::vector<int32_t> &inde
         g_ed.out_cap = n;
     }
     RankArgs a;
-    a.scores = d_scores; a.test = g_ed.test; a.all = g_ed.all; a.n_all = (long long)g_eh.all.size();
+    a.scores = d_scores; a.test = g_ed.test; a.all = g_ed.all; a.all_t = g_ed.all_t; a.n_all = (long long)g_eh.all.size();
     a.head_lef = g_ed.head_lef; a.head_rig = g_ed.head_rig; a.tail_lef = g_ed.tail_lef; a.tail_rig = g_ed.tail_rig;
     a.head_type = g_ed.head_type; a.tail_type = g_ed.tail_type;
     a.sup_lef = g_ed.sup_lef; a.sup_rig = g_ed.sup_rig; a.sub_lef = g_ed.sub_lef; a.sub_rig = g_ed.sub_rig;
@@ -666,7 +688,7 @@ int kge_link_prediction(const kge_model_desc *m, const float *const tables[KGE_M
     if ((rc = hip_check(hipMemcpyAsync(d_hd, hd.data(), sizeof(int32_t) * (size_t)n_req, hipMemcpyHostToDevice, stream), "upload req"))) return rc;
     if ((rc = hip_check(hipMemcpyAsync(d_fixed, fixed.data(), sizeof(int32_t) * (size_t)n_req, hipMemcpyHostToDevice, stream), "upload req"))) return rc;
     RankArgs a;
-    a.test = g_ed.test; a.all = g_ed.all; a.n_all = (long long)g_eh.all.size();
+    a.test = g_ed.test; a.all = g_ed.all; a.all_t = g_ed.all_t; a.n_all = (long long)g_eh.all.size();
     a.head_lef = g_ed.head_lef; a.head_rig = g_ed.head_rig; a.tail_lef = g_ed.tail_lef; a.tail_rig = g_ed.tail_rig;
     a.head_type = g_ed.head_type; a.tail_type = g_ed.tail_type;
     a.sup_lef = g_ed.sup_lef; a.sup_rig = g_ed.sup_rig; a.sub_lef = g_ed.sub_lef; a.sub_rig = g_ed.sub_rig;
