@@ -551,6 +551,102 @@ class Config(object):
         self.trainModel.predict = out
         return out.cpu().numpy()
 
+    # ------------------------------------------------------------------------------------------
+    # triple classification and the predict_* helpers (Config.py:83-151, 491-516, 574-663)
+    # ------------------------------------------------------------------------------------------
+    def _tc_buffers(self, prefix, n):
+        for side in ("pos", "neg"):
+            for col in ("h", "t", "r"):
+                arr = np.zeros(n, dtype=np.int64)
+                setattr(self, "%s_%s_%s" % (prefix, side, col), arr)
+                setattr(self, "%s_%s_%s_addr" % (prefix, side, col), arr.ctypes.data)
+
+    def init_valid_triple_classification(self):
+        """Evaluation files + the buffers getValidBatch / getBestThreshold fill (Config.py:123-151)."""
+        self.lib.kge_clear_error()
+        self.lib.importTestFiles()
+        self.lib.importTypeFiles()
+        _lib.raise_if_error(self.lib)
+        self.testTotal = self.lib.getTestTotal()
+        self.validTotal = self.lib.getValidTotal()
+        self._tc_buffers("valid", self.validTotal)
+        self.relThresh = np.zeros(self.lib.getRelationTotal(), dtype=np.float32)
+        self.relThresh_addr = self.relThresh.ctypes.data
+        self.acc = np.zeros(1, dtype=np.float32)
+        self.acc_addr = self.acc.ctypes.data
+
+    def init_triple_classification(self):
+        """The same plus the test-set buffers (Config.py:83-120)."""
+        self.init_valid_triple_classification()
+        self._tc_buffers("test", self.testTotal)
+
+    def _fit_thresholds(self):
+        """Per-relation thresholds from the validation positives and their type-constrained negatives."""
+        L = self.lib
+        L.getValidBatch(self.valid_pos_h_addr, self.valid_pos_t_addr, self.valid_pos_r_addr,
+                        self.valid_neg_h_addr, self.valid_neg_t_addr, self.valid_neg_r_addr)
+        _lib.raise_if_error(L)
+        res_pos = np.ascontiguousarray(self.test_step(self.valid_pos_h, self.valid_pos_t, self.valid_pos_r).reshape(-1), dtype=np.float32)
+        res_neg = np.ascontiguousarray(self.test_step(self.valid_neg_h, self.valid_neg_t, self.valid_neg_r).reshape(-1), dtype=np.float32)
+        L.getBestThreshold(self.relThresh_addr, res_pos.ctypes.data, res_neg.ctypes.data)
+
+    def test(self):
+        """Triple classification on the test set with thresholds fitted on the validation set, and / or link prediction,
+        as the flags say (Config.py:491-516).  Returns a dict: {"acc": ..} and / or the link-prediction metrics."""
+        import time
+        t0 = time.time()
+        result = {}
+        if self.test_triple_classification:
+            if not hasattr(self, "test_pos_h"):
+                self.init_triple_classification()
+            L = self.lib
+            self._fit_thresholds()
+            L.getTestBatch(self.test_pos_h_addr, self.test_pos_t_addr, self.test_pos_r_addr,
+                           self.test_neg_h_addr, self.test_neg_t_addr, self.test_neg_r_addr)
+            res_pos = np.ascontiguousarray(self.test_step(self.test_pos_h, self.test_pos_t, self.test_pos_r).reshape(-1), dtype=np.float32)
+            res_neg = np.ascontiguousarray(self.test_step(self.test_neg_h, self.test_neg_t, self.test_neg_r).reshape(-1), dtype=np.float32)
+            L.test_triple_classification(self.relThresh_addr, res_pos.ctypes.data, res_neg.ctypes.data, self.acc_addr)
+            _lib.raise_if_error(L)
+            result["acc"] = float(self.acc[0])
+        if self.test_link_prediction:
+            result.update(self.link_prediction()[1])
+        print("\nElapsed test time (seconds): {}".format(time.time() - t0))
+        return result
+
+    def _top_k(self, scores, k):
+        res = np.asarray(scores).reshape(-1).argsort()[:k]
+        print(res)
+        return res
+
+    def predict_head_entity(self, t, r, k):
+        """The k head entities that score best for (?, t, r) (Config.py:574-593)."""
+        ar = np.arange(self.entTotal)
+        return self._top_k(self.test_step(ar, np.full(self.entTotal, t), np.full(self.entTotal, r)), k)
+
+    def predict_tail_entity(self, h, r, k):
+        """The k tail entities that score best for (h, ?, r) (Config.py:595-614)."""
+        ar = np.arange(self.entTotal)
+        return self._top_k(self.test_step(np.full(self.entTotal, h), ar, np.full(self.entTotal, r)), k)
+
+    def predict_relation(self, h, t, k):
+        """The k relations that score best for (h, t, ?) (Config.py:616-635; TransR's predict op uses the matrix of
+        the FIRST relation of a call, TransR.py:83, like the reference)."""
+        ar = np.arange(self.relTotal)
+        return self._top_k(self.test_step(np.full(self.relTotal, h), np.full(self.relTotal, t), ar), k)
+
+    def predict_triple(self, h, t, r, thresh=None):
+        """Is (h, t, r) correct?  Score below `thresh`, or below the relation's threshold fitted on the validation set
+        (Config.py:637-663).  Prints the reference's message and also returns the verdict."""
+        res = float(self.test_step(np.array([h]), np.array([t]), np.array([r])).reshape(-1)[0])
+        if thresh is None:
+            if not hasattr(self, "valid_pos_h"):
+                self.init_triple_classification()
+            self._fit_thresholds()
+            thresh = float(self.relThresh[r])
+        ok = res < thresh
+        print("triple (%d,%d,%d) is %s" % (h, t, r, "correct" if ok else "wrong"))
+        return ok
+
     @staticmethod
     def _lp_sums(out, test_head=True):
         """Un-normalised accumulators of main_spark.py:430-448 over the rows of `out` (they add across test-set slices)."""

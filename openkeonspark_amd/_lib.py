@@ -46,6 +46,11 @@ def _declare(L):
     L.testHead.argtypes = [i64, vp]
     L.testHead.restype = ctypes.POINTER(ctypes.c_int64 * 8)
     L.kge_link_prediction.argtypes = [ctypes.POINTER(ModelDesc), ctypes.POINTER(vp), i64, i64, i64, vp, vp]
+    # triple classification (Config.py:41-46 -- with all FOUR arguments of test_triple_classification declared)
+    L.getValidBatch.argtypes = [vp] * 6
+    L.getTestBatch.argtypes = [vp] * 6
+    L.getBestThreshold.argtypes = [vp] * 3
+    L.test_triple_classification.argtypes = [vp] * 4
     # (2) engine
     L.kge_last_error.restype = ctypes.c_size_t
     L.kge_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]

@@ -103,3 +103,39 @@ def test_relation_grouped_ranker_equals_generic_predict_path(model, test_head):
     L.kge_set_option(b"lp_v1", 0)
     sub, _ = con.link_prediction(first=5, count=17, test_head=test_head)
     assert np.array_equal(sub, outs[1][0][5:22])
+
+
+def test_config_test_and_predict_helpers(capsys):
+    """Config.test() (triple classification with validation-fitted thresholds + link prediction) and the predict_*
+    helpers of the reference class (Config.py:491-516, 574-663) against their definitions over test_step."""
+    import openkeonspark_amd as pkg
+    con = pkg.Config()
+    con.set_in_path(os.path.join(GOLDEN, "kg_small"))
+    con.set_work_threads(1); con.set_dimension(16)
+    con.set_test_link_prediction(True); con.set_test_triple_classification(True)
+    con.init()
+    con.set_model_and_session(pkg.TransE)
+    for t in con._tables:
+        t.mul_(3.0)
+    res = con.test()
+    assert 0.0 <= res["acc"] <= 1.0 and res["r_filter_rank"] >= 1.0
+    # the accuracy is the definition: positives at or below, negatives above the relation's fitted threshold
+    pos = con.test_step(con.test_pos_h, con.test_pos_t, con.test_pos_r).reshape(-1)
+    neg = con.test_step(con.test_neg_h, con.test_neg_t, con.test_neg_r).reshape(-1)
+    # (relations without validation triples have no threshold and are skipped, Test.h:353)
+    seen = np.isin(con.test_pos_r, np.unique(con.valid_pos_r))
+    want = ((pos <= con.relThresh[con.test_pos_r])[seen].sum() + (neg > con.relThresh[con.test_neg_r])[seen].sum()) / (2.0 * seen.sum())
+    assert abs(res["acc"] - want) < 1e-6
+    E, R = con.entTotal, con.relTotal
+    ar = np.arange(E)
+    heads = con.predict_head_entity(5, 2, 7)
+    assert heads.tolist() == con.test_step(ar, np.full(E, 5), np.full(E, 2)).reshape(-1).argsort()[:7].tolist()
+    tails = con.predict_tail_entity(9, 1, 4)
+    assert tails.tolist() == con.test_step(np.full(E, 9), ar, np.full(E, 1)).reshape(-1).argsort()[:4].tolist()
+    rels = con.predict_relation(3, 8, 3)
+    assert rels.tolist() == con.test_step(np.full(R, 3), np.full(R, 8), np.arange(R)).reshape(-1).argsort()[:3].tolist()
+    s = float(con.test_step([3], [8], [rels[0]])[0])
+    assert con.predict_triple(3, 8, int(rels[0]), thresh=s + 1.0) is True
+    assert con.predict_triple(3, 8, int(rels[0]), thresh=s - 1.0) is False
+    assert con.predict_triple(3, 8, int(rels[0])) in (True, False)
+    assert "is correct" in capsys.readouterr().out
