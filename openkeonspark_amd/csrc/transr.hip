@@ -346,26 +346,45 @@ constexpr int LDB2 = NT2 * 16;   // [k][j] layout, stride 208 = 16 mod 32: lanes
 // Staging: every thread issues ALL its global loads of a chunk back to back into registers (unconditional, with
 // clamped addresses -- the compiler serialises conditional loads, one memory latency each), the chunk after the one
 // being multiplied is in flight during the MFMA loop, and invalid elements are zeroed on the way into LDS.
-// VEC (both dims multiples of 4): 16-byte loads; otherwise a scalar, conditional fallback (odd test shapes).
+// The MFMA block is branch-free (a condition per tile puts every MFMA in its own basic block): the kernels are
+// instantiated for NT = 7 or 13 column tiles (dims <= 112 / <= 208, multiples of 4) and always multiply all of them --
+// padding rows and columns are zero in LDS; other shapes take the 32x32x2 kernels.
 // RT2 16-row sub-tiles per wave: a workgroup covers 64*RT2 rows, so a relation's 160 kB matrix (which comes from the
 // Infinity Cache, not HBM) is re-read once per 128 rows: 39 flop per byte instead of 24.
 constexpr int RT2 = 2;
 constexpr int RW2 = RM2 * RT2;   // rows per workgroup (128)
 
-template <int MODE, bool VEC>
-__global__ __launch_bounds__(256) void rows_gemm2_kernel(GemmArgs a) {
+template <int MODE, int NT, int NS>
+__device__ __forceinline__ void gemm2_mfma_block(const float *__restrict__ As, const float *__restrict__ Bs, f32x4 (&acc)[RT2][NT], int wave, int lane) {
+    constexpr int LDBN = NT * 16;
+#pragma unroll
+    for (int ks = 0; ks < KC2; ks += 4) {
+        const int kk = ks + (lane >> 4);
+        float av[NS];
+#pragma unroll
+        for (int s2 = 0; s2 < NS; s2++) av[s2] = As[((4 * s2 + wave) * 16 + (lane & 15)) * LDA2 + kk];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const float bv = MODE == GEMM_PROJECT ? Bs[kk * LDBN + t * 16 + (lane & 15)] : Bs[(t * 16 + (lane & 15)) * LDA2 + kk];
+#pragma unroll
+            for (int s2 = 0; s2 < NS; s2++) acc[s2][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv, acc[s2][t], 0, 0, 0);
+        }
+    }
+}
+
+template <int MODE, int NT>
+__global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // two workgroups per CU: their barriers and load waits overlap
+    constexpr int LDBN = NT * 16;    // [k][j] stride: 112 or 208 floats, both = 16 mod 32 banks
     const int tile = blockIdx.x;
     if (tile >= a.n_tiles[0]) return;
     __shared__ __attribute__((aligned(16))) float As[RW2 * LDA2];
-    __shared__ __attribute__((aligned(16))) float Bs[(MODE == GEMM_PROJECT) ? KC2 * LDB2 : LDB2 * LDA2];
+    __shared__ __attribute__((aligned(16))) float Bs[(MODE == GEMM_PROJECT) ? KC2 * LDBN : LDBN * LDA2];
     __shared__ int s_slot[RW2], s_ent[RW2];
     const int r = a.tile_rel[tile];
     const int row0 = a.tile_row0[tile];
     const int rows = min(RW2, a.bucket_start[r + 1] - row0);
     const int K = MODE == GEMM_PROJECT ? a.De : a.Dr;
-    const int N = MODE == GEMM_PROJECT ? a.Dr : a.De;
-    const int ncols = min(LDB2, N);
-    const int nt = (ncols + 15) >> 4;
+    const int ncols = MODE == GEMM_PROJECT ? a.Dr : a.De;     // <= LDBN, multiple of 4
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < RW2) {
@@ -375,17 +394,18 @@ __global__ __launch_bounds__(256) void rows_gemm2_kernel(GemmArgs a) {
     }
     __syncthreads();
     const float *M = a.mat + (long long)r * a.De * a.Dr;
-    f32x4 acc[RT2][NT2];
+    f32x4 acc[RT2][NT];
 #pragma unroll
     for (int s2 = 0; s2 < RT2; s2++)
 #pragma unroll
-        for (int t = 0; t < NT2; t++) acc[s2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; t++) acc[s2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // sub-tile s2 of wave w covers rows (4*s2 + w)*16 ..: interleaved, so a short tile keeps all four waves busy
+    const int n_live = (wave * 16 < rows ? 1 : 0) + ((4 + wave) * 16 < rows ? 1 : 0);
     constexpr int AQ = KC2 / 4;                       // float4 per A row chunk
     constexpr int NA = (RW2 * AQ + 255) / 256;        // A float4 loads per thread (5)
-    constexpr int BROWS = MODE == GEMM_PROJECT ? KC2 : LDB2;
-    constexpr int BQ = MODE == GEMM_PROJECT ? LDB2 / 4 : KC2 / 4;
-    constexpr int NB = (BROWS * BQ + 255) / 256;      // B float4 loads per thread (9)
+    constexpr int BROWS = MODE == GEMM_PROJECT ? KC2 : LDBN;
+    constexpr int BQ = MODE == GEMM_PROJECT ? LDBN / 4 : KC2 / 4;
+    constexpr int NB = (BROWS * BQ + 255) / 256;      // B float4 loads per thread (9 at NT = 13)
     float4 ra[NA], rb[NB];
 #define KGE_LOAD_CHUNK(k0_)                                                                                                  \
     {                                                                                                                        \
@@ -407,10 +427,10 @@ __global__ __launch_bounds__(256) void rows_gemm2_kernel(GemmArgs a) {
             rb[u] = *reinterpret_cast<const float4 *>(src);                                                                  \
         });                                                                                                                  \
     }
-    if (VEC) KGE_LOAD_CHUNK(0)
+    KGE_LOAD_CHUNK(0)
     for (int k0 = 0; k0 < K; k0 += KC2) {
         if (k0 > 0) __syncthreads();          // the previous chunk's MFMA reads are done
-        if (VEC) {
+        {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             static_for<0, NA>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
@@ -429,7 +449,7 @@ __global__ __launch_bounds__(256) void rows_gemm2_kernel(GemmArgs a) {
                 if (idx < BROWS * BQ) {
                     const int rr = idx / BQ, q = idx - rr * BQ;
                     if (MODE == GEMM_PROJECT) {
-                        *reinterpret_cast<float4 *>(&Bs[rr * LDB2 + 4 * q]) = (k0 + rr < K && 4 * q < ncols) ? rb[u] : z;
+                        *reinterpret_cast<float4 *>(&Bs[rr * LDBN + 4 * q]) = (k0 + rr < K && 4 * q < ncols) ? rb[u] : z;
                     } else {
                         const float4 v = (rr < ncols && k0 + 4 * q < K) ? rb[u] : z;
                         float2 *dst = reinterpret_cast<float2 *>(&Bs[rr * LDA2 + 4 * q]);
@@ -438,53 +458,21 @@ __global__ __launch_bounds__(256) void rows_gemm2_kernel(GemmArgs a) {
                     }
                 }
             });
-        } else {   // scalar fallback for dims that are not multiples of 4
-            for (int idx = tid; idx < RW2 * KC2; idx += 256) {
-                const int i = idx / KC2, kk = idx - i * KC2, kg = k0 + kk;
-                float v = 0.f;
-                if (i < rows && kg < K)
-                    v = MODE == GEMM_PROJECT ? a.ent[(long long)s_ent[i] * a.De + kg] : a.GP[(long long)s_slot[i] * a.Dr + kg];
-                As[i * LDA2 + kk] = v;
-            }
-            if (MODE == GEMM_PROJECT) {
-                for (int idx = tid; idx < KC2 * LDB2; idx += 256) {
-                    const int kk = idx / LDB2, j = idx - kk * LDB2, kg = k0 + kk;
-                    Bs[kk * LDB2 + j] = (kg < K && j < ncols) ? M[(long long)kg * a.Dr + j] : 0.f;
-                }
-            } else {
-                for (int idx = tid; idx < LDB2 * KC2; idx += 256) {
-                    const int j = idx / KC2, kk = idx - j * KC2, kg = k0 + kk;
-                    Bs[j * LDA2 + kk] = (kg < K && j < ncols) ? M[(long long)j * a.Dr + kg] : 0.f;
-                }
-            }
         }
         __syncthreads();
-        if (VEC && k0 + KC2 < K) KGE_LOAD_CHUNK(k0 + KC2)   // in flight during the MFMA loop
-#pragma unroll
-        for (int ks = 0; ks < KC2; ks += 4) {
-            const int kk = ks + (lane >> 4);
-            float av[RT2];
-#pragma unroll
-            for (int s2 = 0; s2 < RT2; s2++) av[s2] = As[((4 * s2 + wave) * 16 + (lane & 15)) * LDA2 + kk];
-#pragma unroll
-            for (int t = 0; t < NT2; t++) {
-                if (t < nt) {
-                    const float bv = MODE == GEMM_PROJECT ? Bs[kk * LDB2 + t * 16 + (lane & 15)] : Bs[(t * 16 + (lane & 15)) * LDA2 + kk];
-#pragma unroll
-                    for (int s2 = 0; s2 < RT2; s2++)
-                        if ((4 * s2 + wave) * 16 < rows) acc[s2][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv, acc[s2][t], 0, 0, 0);
-                }
-            }
-        }
+        if (k0 + KC2 < K) KGE_LOAD_CHUNK(k0 + KC2)   // in flight during the MFMA loop
+        // one block variant only (two would each get their own accumulator registers): a wave with any live row multiplies
+        // both of its sub-tiles, the padding rows being zero
+        if (n_live > 0) gemm2_mfma_block<MODE, NT, RT2>(As, Bs, acc, wave, lane);
     }
 #undef KGE_LOAD_CHUNK
 #pragma unroll
     for (int s2 = 0; s2 < RT2; s2++) {
         if ((4 * s2 + wave) * 16 >= rows) continue;
 #pragma unroll
-        for (int t = 0; t < NT2; t++) {
+        for (int t = 0; t < NT; t++) {
             const int j = t * 16 + (lane & 15);
-            if (t < nt && j < ncols) {
+            if (j < ncols) {
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
                     const int row = (4 * s2 + wave) * 16 + 4 * (lane >> 4) + v;
@@ -499,15 +487,19 @@ __global__ __launch_bounds__(256) void rows_gemm2_kernel(GemmArgs a) {
     }
 }
 
-// wgrad v2: g_M[r][i][j] += sum over rows of ent[e_row][i] * GP[slot_row][j].  A workgroup owns SPAN2 consecutive
-// 128-row tiles of the relation-sorted job list (256 rows between flushes) and ALL <= 13 x 13 output tiles, so the
-// rows are streamed exactly once; wave w takes output row-tiles w, w+4, w+8, w+12 and every column tile.
-// Rows are staged 32 at a time, the next 32 in flight during the MFMA loop.
+// wgrad v2 (dims 196..208, multiples of 4: the full 13 x 13 output tile grid): g_M[r][i][j] += sum over rows of
+// ent[e_row][i] * GP[slot_row][j].  A workgroup owns SPAN2 consecutive 128-row tiles of the relation-sorted job list
+// (256 rows between flushes) and ALL output tiles, so the rows are streamed exactly once; wave w takes output row-tiles
+// w, w+4, w+8 with every column tile, and the 13th row-tile's column tiles w, w+4, w+8, w+12 (43 / 42 of the 169 tiles
+// per wave; the 4th extra tile of waves 1..3 does not exist: it is computed on a clamped column and dropped at the flush,
+// which keeps the MFMA block branch-free).  Rows are staged 32 at a time, the next 32 in flight during the MFMA loop.
+// A relation whose whole bucket lies inside the span has one owner: its matrix gradient is stored, not added with
+// atomics (the accumulator is zero).
 constexpr int SPAN2 = 2;
 constexpr int WK2 = 32;                 // rows per staged chunk (8 k-steps)
-constexpr int WI2 = 4;                  // output row-tiles per wave: ceil(13 / 4)
+constexpr int WI2 = 3;                  // full output row-tiles per wave (row tiles 0..11)
+constexpr int WX2 = 4;                  // column tiles of row tile 12 per wave
 
-template <bool VEC>
 __global__ __launch_bounds__(256) void wgrad2_kernel(GemmArgs a, float *__restrict__ g_mat) {
     const int n_tiles = a.n_tiles[0];
     const int t0 = blockIdx.x * SPAN2;
@@ -517,16 +509,20 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(GemmArgs a, float *__restri
     __shared__ __attribute__((aligned(16))) float Gs[WK2 * LDB2];    // [row k][j]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nti = (a.De + 15) >> 4, ntj = (a.Dr + 15) >> 4;
-    f32x4 acc[WI2][NT2];
+    f32x4 acc[WI2][NT2], accx[WX2];
 #pragma unroll
     for (int s2 = 0; s2 < WI2; s2++)
 #pragma unroll
         for (int t2 = 0; t2 < NT2; t2++) acc[s2][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int x2 = 0; x2 < WX2; x2++) accx[x2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // rows [span_lo, span_hi) of the sorted job list belong to this workgroup
+    const int span_lo = a.tile_row0[t0];
+    const int span_hi = a.tile_row0[t1 - 1] + min(RW2, a.bucket_start[a.tile_rel[t1 - 1] + 1] - a.tile_row0[t1 - 1]);
     constexpr int Q = LDB2 / 4;                       // float4 per staged row (52)
     constexpr int NL = (WK2 * Q + 255) / 256;         // float4 loads per thread and operand (7)
     float4 rx[NL], rg[NL];
-    const int qx = a.De / 4, qg = a.Dr / 4;           // valid float4 per row (VEC only)
+    const int qx = a.De / 4, qg = a.Dr / 4;           // valid float4 per row
 #define KGE_WLOAD(row_first_, crow_)                                                                          \
     {                                                                                                         \
         static_for<0, NL>([&](auto uc) {                                                                      \
@@ -539,22 +535,36 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(GemmArgs a, float *__restri
             rg[u] = *reinterpret_cast<const float4 *>(a.GP + (long long)sl * a.Dr + 4 * min(q, qg - 1));      \
         });                                                                                                   \
     }
+#define KGE_WPUT(i_, j_, v_)                                                                                  \
+    if ((i_) < a.De && (j_) < a.Dr && (v_) != 0.f) {                                                          \
+        if (sole) G[(long long)(i_) * a.Dr + (j_)] = (v_);                                                    \
+        else __builtin_amdgcn_global_atomic_fadd_f32(                                                         \
+                (__attribute__((address_space(1))) float *)(G + (long long)(i_) * a.Dr + (j_)), (v_));        \
+    }
 #define KGE_WFLUSH(rel_)                                                                                      \
     {                                                                                                         \
         float *G = g_mat + (long long)(rel_) * a.De * a.Dr;                                                   \
+        const bool sole = a.bucket_start[rel_] >= span_lo && a.bucket_start[(rel_) + 1] <= span_hi;           \
         _Pragma("unroll") for (int s2 = 0; s2 < WI2; s2++) {                                                  \
             _Pragma("unroll") for (int t2 = 0; t2 < NT2; t2++) {                                              \
                 const int j = t2 * 16 + (lane & 15);                                                          \
-                if (wave + 4 * s2 < nti && t2 < ntj) {                                                        \
-                    _Pragma("unroll") for (int v = 0; v < 4; v++) {                                           \
-                        const int i = (wave + 4 * s2) * 16 + 4 * (lane >> 4) + v;                             \
-                        if (i < a.De && j < a.Dr && acc[s2][t2][v] != 0.f)                                    \
-                            __builtin_amdgcn_global_atomic_fadd_f32(                                          \
-                                (__attribute__((address_space(1))) float *)(G + (long long)i * a.Dr + j), acc[s2][t2][v]); \
-                    }                                                                                         \
+                _Pragma("unroll") for (int v = 0; v < 4; v++) {                                               \
+                    const int i = (wave + 4 * s2) * 16 + 4 * (lane >> 4) + v;                                 \
+                    KGE_WPUT(i, j, acc[s2][t2][v])                                                            \
                 }                                                                                             \
                 acc[s2][t2] = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
             }                                                                                                 \
+        }                                                                                                     \
+        _Pragma("unroll") for (int x2 = 0; x2 < WX2; x2++) {                                                  \
+            const int jt = wave + 4 * x2;                                                                     \
+            if (jt < NT2) {                                                                                   \
+                const int j = jt * 16 + (lane & 15);                                                          \
+                _Pragma("unroll") for (int v = 0; v < 4; v++) {                                               \
+                    const int i = 12 * 16 + 4 * (lane >> 4) + v;                                              \
+                    KGE_WPUT(i, j, accx[x2][v])                                                               \
+                }                                                                                             \
+            }                                                                                                 \
+            accx[x2] = f32x4{0.f, 0.f, 0.f, 0.f};                                                             \
         }                                                                                                     \
     }
     int t = t0, c0 = 0;
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(GemmArgs a, float *__restri
     int rows_t = min(RW2, a.bucket_start[rel + 1] - a.tile_row0[t]);
     int row_first = a.tile_row0[t];
     int crow = min(WK2, rows_t);
-    if (VEC) KGE_WLOAD(row_first, crow)
+    KGE_WLOAD(row_first, crow)
     bool first = true;
     while (true) {
         if (rel != r_cur) {
@@ -572,7 +582,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(GemmArgs a, float *__restri
         }
         if (!first) __syncthreads();
         first = false;
-        if (VEC) {
+        {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             static_for<0, NL>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
@@ -583,18 +593,6 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(GemmArgs a, float *__restri
                     *reinterpret_cast<float4 *>(&Gs[kk * LDB2 + 4 * q]) = (kk < crow && q < qg) ? rg[u] : z;
                 }
             });
-        } else {
-            for (int idx = tid; idx < WK2 * LDB2; idx += 256) {
-                const int kk = idx / LDB2, c = idx - kk * LDB2;
-                float x = 0.f, gv = 0.f;
-                if (kk < crow) {
-                    const int sl = a.sorted_slots[row_first + kk];
-                    if (c < a.De) x = a.ent[(long long)a.job_ent[sl] * a.De + c];
-                    if (c < a.Dr) gv = a.GP[(long long)sl * a.Dr + c];
-                }
-                Xs[idx] = x;
-                Gs[idx] = gv;
-            }
         }
         __syncthreads();
         // the next chunk: same tile, or the first chunk of the next tile of the span
@@ -608,22 +606,25 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(GemmArgs a, float *__restri
             n_rows = min(RW2, a.bucket_start[n_rel + 1] - nrow0);
             n_first = nrow0 + nc;
             n_crow = min(WK2, n_rows - nc);
-            if (VEC) KGE_WLOAD(n_first, n_crow)
+            KGE_WLOAD(n_first, n_crow)
         }
 #pragma unroll
         for (int ks = 0; ks < WK2; ks += 4) {
             const int kk = ks + (lane >> 4);
             float av[WI2];
 #pragma unroll
-            for (int s2 = 0; s2 < WI2; s2++) av[s2] = Xs[kk * LDB2 + min(wave + 4 * s2, NT2 - 1) * 16 + (lane & 15)];   // A[i][k] = X[row k][i]
+            for (int s2 = 0; s2 < WI2; s2++) av[s2] = Xs[kk * LDB2 + (wave + 4 * s2) * 16 + (lane & 15)];   // A[i][k] = X[row k][i]
+            const float ax = Xs[kk * LDB2 + 12 * 16 + (lane & 15)];                                        // row tile 12
 #pragma unroll
             for (int t2 = 0; t2 < NT2; t2++) {
-                if (t2 < ntj) {
-                    const float bv = Gs[kk * LDB2 + t2 * 16 + (lane & 15)];   // B[k][j] = GP[row k][j]
+                const float bv = Gs[kk * LDB2 + t2 * 16 + (lane & 15)];   // B[k][j] = GP[row k][j]
 #pragma unroll
-                    for (int s2 = 0; s2 < WI2; s2++)
-                        if (wave + 4 * s2 < nti) acc[s2][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv, acc[s2][t2], 0, 0, 0);
-                }
+                for (int s2 = 0; s2 < WI2; s2++) acc[s2][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv, acc[s2][t2], 0, 0, 0);
+            }
+#pragma unroll
+            for (int x2 = 0; x2 < WX2; x2++) {
+                const float bv = Gs[kk * LDB2 + min(wave + 4 * x2, NT2 - 1) * 16 + (lane & 15)];
+                accx[x2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bv, accx[x2], 0, 0, 0);
             }
         }
         if (!more) break;
@@ -632,6 +633,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(GemmArgs a, float *__restri
     KGE_WFLUSH(r_cur)
 #undef KGE_WLOAD
 #undef KGE_WFLUSH
+#undef KGE_WPUT
 }
 
 int bits_for(int64_t v) { int b = 1; while ((int64_t(1) << b) <= v) b++; return b; }
@@ -657,8 +659,8 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     rc = hip_check(rocprim::radix_sort_pairs(g_w.sort_tmp, tmp, g_w.keys, g_w.keys2, g_w.vals, g_w.vals2, (size_t)slots, 0,
                                              bits_for(R), stream), "transr bucket sort");
     if (rc) return rc;
-    // v2 kernels (16x16x4 MFMA, 64-row tiles) whenever one workgroup covers all columns of both dimensions
-    const bool v2 = De <= LDB2 && Dr <= LDB2 && engine().transr_v1 != 1;
+    // v2 kernels (16x16x4 MFMA, 128-row tiles): dims multiples of 4 up to 208, one workgroup covers all columns
+    const bool v2 = De % 4 == 0 && Dr % 4 == 0 && De >= 4 && Dr >= 4 && De <= LDB2 && Dr <= LDB2 && engine().transr_v1 != 1;
     hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(1024), 0, stream, g_w.keys2, (int)slots, (int)R, g_w.bucket_start,
                        g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, v2 ? 7 : 5);
     GemmArgs ga;
@@ -667,9 +669,8 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     ga.tile_rel = g_w.tile_rel; ga.tile_row0 = g_w.tile_row0; ga.n_tiles = g_w.n_tiles;
     ga.De = De; ga.Dr = Dr;
     const unsigned max_tiles = (unsigned)(slots / (v2 ? RW2 : 32) + R + 1);
-    const bool vec = De % 4 == 0 && Dr % 4 == 0;
-    if (v2 && vec) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, true>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
-    else if (v2) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, false>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
+    if (v2 && Dr <= 112) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, 7>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
+    else if (v2) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, 13>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
     else hipLaunchKernelGGL((rows_gemm_kernel<GEMM_PROJECT>), dim3(max_tiles, (Dr + TN - 1) / TN), dim3(256), 0, stream, ga);
     rc = hip_check(hipMemsetAsync(g_w.GP, 0, sizeof(float) * (size_t)slots * Dr, stream), "zero GP");
     if (rc) return rc;
@@ -678,13 +679,13 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     if (rc) return rc;
     if (v2) {
         const dim3 wg((max_tiles + SPAN2 - 1) / SPAN2, 1);
-        if (vec) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, true>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
-        else hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, false>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
-        // the all-output-tiles wgrad pays one 160 kB atomic flush per relation change: only with well-filled buckets
-        // (measured: 316 vs 400 us at 574 rows per relation, 131 vs 77 us at 46)
-        if (slots >= 256 * R || engine().transr_v1 == 2) {
-            if (vec) hipLaunchKernelGGL((wgrad2_kernel<true>), wg, dim3(256), 0, stream, ga, grads[2]);
-            else hipLaunchKernelGGL((wgrad2_kernel<false>), wg, dim3(256), 0, stream, ga, grads[2]);
+        if (De <= 112) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 7>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
+        else hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 13>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
+        // the all-output-tiles wgrad (full 13 x 13 tile grid only) pays one 160 kB flush per relation change: only with
+        // well-filled buckets (measured: 316 vs 400 us at 574 rows per relation, 131 vs 77 us at 46)
+        const bool full_grid = De > 192 && Dr > 192;
+        if (full_grid && (slots >= 256 * R || engine().transr_v1 == 2)) {
+            hipLaunchKernelGGL(wgrad2_kernel, wg, dim3(256), 0, stream, ga, grads[2]);
         } else {
             const int tiles_i1 = (De + 31) / 32;
             const int wgt = WG_TILES * 32 / RW2;   // the same 256 rows between flushes as with 32-row tiles
