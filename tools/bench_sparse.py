@@ -29,7 +29,13 @@ def main():
     import openkeonspark_amd as ok
     from openkeonspark_amd.synthetic import generate_triples
     t0 = time.time()
-    h, t, r = generate_triples(a.entities, a.relations, a.triples, seed=5, dup_frac=0.0, ent_exponent=a.ent_exponent)
+    if a.ent_exponent == 0.0:   # uniform popularity: plain draws (the Zipf inverse-CDF search takes minutes at 500 M triples)
+        rng = np.random.default_rng(5)
+        h = rng.integers(0, a.entities, a.triples, dtype=np.int64)
+        t = rng.integers(0, a.entities, a.triples, dtype=np.int64)
+        r = rng.integers(0, a.relations, a.triples, dtype=np.int64)
+    else:
+        h, t, r = generate_triples(a.entities, a.relations, a.triples, seed=5, dup_frac=0.0, ent_exponent=a.ent_exponent)
     t_gen = time.time() - t0
     con = ok.Config()
     con.set_work_threads(a.threads)
