@@ -469,8 +469,7 @@ class Config(object):
             self._sparse_buf = buf
         st = self._stream()
         buf["dst"].fill_(-1)
-        if dev_batch.shape[1] < stride * (1 + n_neg):
-            raise KgeError("sparse step: batch buffer smaller than the record stride")
+        # (the BATCH arrays keep their own, local stride; only the record slots are padded to the largest slice)
         _lib.check(self.lib.kge_transe_emit_records(
             ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(),
             dev_batch[0].data_ptr(), dev_batch[1].data_ptr(), dev_batch[2].data_ptr(), n_pos, n_neg,

@@ -12,7 +12,7 @@ from conftest import GOLDEN, ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=False):
+def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=False, nbatches=10):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -23,7 +23,7 @@ def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=
     import openkeonspark_amd as pkg
     con = pkg.Config()
     con.set_in_path(os.path.join(GOLDEN, "kg_small"))
-    con.set_work_threads(8); con.set_bern(1); con.set_dimension(48); con.set_nbatches(10)  # B = 600
+    con.set_work_threads(8); con.set_bern(1); con.set_dimension(48); con.set_nbatches(nbatches)  # B = 600 by default
     con.set_ent_neg_rate(3); con.set_alpha(0.02); con.set_opt_method(opt)
     con.sparse_rows = sparse
     con.prefetch_sampling = prefetch   # (data-parallel default: on; then the rng states run one batch ahead)
@@ -144,3 +144,26 @@ def test_link_prediction_split_over_ranks(tmp_path):
         for k in one:
             assert abs(one[k] - two[k]) <= 1e-12 * max(1.0, abs(one[k])), k
     assert one["r_filter_rank"] >= 1.0 and one["l_rank"] >= one["l_filter_rank"]
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_rank_with_an_empty_slice(tmp_path, sparse):
+    """B = 3 positions over 8 virtual threads: rank 1 (threads 4..7) owns NO position of any batch.  It must still
+    advance the rng streams, join the exchange and apply the same update (ragged / empty inputs of the reference's
+    slice rule, Base.cpp:85-92)."""
+    import torch.multiprocessing as mp
+    port = 30100 + os.getpid() % 1000
+    args1 = (1, port, str(tmp_path), "TransE", "SGD", sparse, False, 2000)
+    args2 = (2, port + 1, str(tmp_path), "TransE", "SGD", sparse, False, 2000)
+    mp.start_processes(_worker, args=args1, nprocs=1, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=args2, nprocs=2, join=True, start_method="spawn")
+    one = np.load(str(tmp_path / "w1_r0.npz"))
+    r0 = np.load(str(tmp_path / "w2_r0.npz"))
+    r1 = np.load(str(tmp_path / "w2_r1.npz"))
+    assert np.array_equal(r0["states"], one["states"]) and np.array_equal(r1["states"], one["states"])
+    assert np.allclose(r0["losses"], one["losses"], rtol=2e-5, atol=0)
+    for k in one.files:
+        if k in ("losses", "states"):
+            continue
+        assert np.array_equal(r0[k], r1[k]), k
+        assert np.array_equal(r0[k], one[k]), k
