@@ -494,3 +494,37 @@ def test_atomic_path_hub_copies_match_oracle(model, copies):
     finally:
         L.kge_set_option(b"float_records", 1)
         L.kge_set_option(b"hub_copies", 1)
+
+
+@pytest.mark.parametrize("model", ["transe", "transh", "transd", "transr"])
+@pytest.mark.parametrize("B,n", [(1, 1), (1, 7), (3, 2)])
+def test_tiny_batches_match_oracle(model, B, n, grad_path):
+    """One positive, a handful of triples: every tile / chunk / bucket is mostly padding."""
+    import torch
+    E, R, D = 37, 3, 36
+    rng = np.random.default_rng(seed_of(model, B, n, "tiny"))
+    params = oracle.init_params(oracle.MODEL_IDS[model], E, R, D, D, seed=8)
+    for k in params:
+        params[k] = (params[k] * 3).astype(np.float32)
+    orc = oracle.Model(model, E, R, D, D, margin=2.0, params=params)
+    bh, bt, br = batch_without_ties(orc, lambda: rand_batch(rng, E, R, B, n, 0, distinct=True), B, n)
+    loss_o, g_o = orc.grad(bh, bt, br, B, n)
+    con = make_engine(model, E, R, D, n, 0, margin=2.0, params=params)
+    dev = torch.from_numpy(np.stack([bh, bt, br]).astype(np.int32)).cuda()
+    con.forward_backward(dev, B, B, B * n)
+    torch.cuda.synchronize()
+    assert abs(float(con._loss.item()) - loss_o) <= RTOL * abs(loss_o) + 1e-12
+    g_g = con.get_gradients()
+    for k in g_o:
+        assert np.abs(g_g[k] - g_o[k]).max() <= RTOL * (np.abs(g_o[k]).max() + 1e-30), k
+    if model == "transe":      # and the integer path on the same tiny batch
+        for g in con._grads:
+            g.zero_()
+        con.forward_counts(dev, B, B, B * n)
+        con.set_opt_method("SGD")
+        before = con.get_parameters()
+        con.apply_counts(B * n)
+        after = con.get_parameters()
+        for k in g_o:
+            upd = (before[k] - after[k]) / con.alpha
+            assert np.abs(upd - g_o[k]).max() <= 1e-4 * (np.abs(g_o[k]).max() + 1e-30), k

@@ -143,3 +143,36 @@ def test_ragged_and_edge_batches(fb_dir):
             for a, b in zip(got, want):
                 assert np.array_equal(a, b), (W, B, n, nr, c)
         assert con.get_stream_states().tolist() == kg.stream_states().tolist()
+
+
+def test_many_negatives_and_saturated_groups(tmp_path):
+    """Edge cases of the lane mapping and of the division-free modulo: more draws per positive than a wave has lanes
+    (1 + 40 + 30 = 71 -> 128 slots), a relation corruption set that leaves exactly ONE candidate (modulo 1), entity
+    groups covering all but one entity (modulo 1 again), against the oracle, bit for bit."""
+    d = str(tmp_path / "kg_dense")
+    os.makedirs(d)
+    E, R = 5, 33
+    trip = []
+    for t in range(1, E):                     # head 0 reaches every other entity through relation 0: tails(0, r0) = E - 1
+        trip.append((0, t, 0))
+    for r in range(R - 1):                    # (1, 2) is linked by all relations but the last: rels(1, 2) = R - 1
+        trip.append((1, 2, r))
+    for h in range(2, E):
+        trip.append((h, (h + 1) % E, 5))
+    open(os.path.join(d, "entity2id.txt"), "w").write("%d\n" % E)
+    open(os.path.join(d, "relation2id.txt"), "w").write("%d\n" % R)
+    with open(os.path.join(d, "train2id.txt"), "w") as f:
+        f.write("%d\n" % len(trip))
+        for h, t, r in trip:
+            f.write("%d %d %d\n" % (h, t, r))
+    for W, bern, B, n, nr in [(2, 1, 40, 40, 30), (3, 0, 17, 63, 1), (1, 1, 9, 1, 0)]:
+        kg = oracle.KG(d, work_threads=W, bern=bern)
+        con = make_config(d, W, bern)
+        seeds = np.ascontiguousarray(kg.stream_states())
+        con.lib.kge_set_stream_states(seeds.ctypes.data, W)
+        for c in range(3):
+            want = kg.sampling(B, n, nr)
+            got = abi_sampling(con, B, n, nr)
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b), (W, bern, B, n, nr, c)
+        assert con.get_stream_states().tolist() == kg.stream_states().tolist()
