@@ -412,6 +412,7 @@ class Config(object):
             if self.world_size != 1:
                 raise KgeError("feeding a host batch is single-process only")
             host = np.stack([np.asarray(batch_h), np.asarray(batch_t), np.asarray(batch_r)]).astype(np.int32)
+            self._check_ids(host)
             dev = torch.from_numpy(host).to(self.device)
             n_pos = host.shape[1] // (1 + n_neg)
             stride = n_pos
@@ -537,12 +538,20 @@ class Config(object):
             self._beta2_power = f(self._beta2_power * f(self.adam_beta2))
         self.global_step += 1
 
+    def _check_ids(self, host):
+        """Caller-supplied ids index device tables directly: an id out of range must fail here, not fault on the GPU."""
+        if host.shape[1] == 0:
+            return
+        if host.min() < 0 or host[:2].max() >= self.entTotal or host[2].max() >= self.relTotal:
+            raise KgeError("entity / relation id out of range in the supplied batch")
+
     def test_step(self, test_h, test_t, test_r):
         '''
         Score triples with the model's predict op (Config.py:478-488)
         '''
         import torch
         host = np.stack([np.asarray(test_h), np.asarray(test_t), np.asarray(test_r)]).astype(np.int32)
+        self._check_ids(host)
         dev = torch.from_numpy(host).to(self.device)
         out = torch.empty(host.shape[1], dtype=torch.float32, device=self.device)
         _lib.check(self.lib.kge_predict(ctypes.byref(self._desc), self._tab_ptrs, dev[0].data_ptr(), dev[1].data_ptr(),

@@ -52,6 +52,7 @@ __device__ __forceinline__ uint64_t mod_magic(uint64_t s, uint64_t d, uint64_t m
 // d < 2^31 known only per thread: two rounds of fp64 reciprocal division; each quotient is < 2^32, so the fp64
 // estimate is within one of the truth and one correction step each makes it exact
 __device__ __forceinline__ uint32_t mod_u64_u32(uint64_t s, uint32_t d) {
+    if (d == 0) return 0;   // a group that already contains every candidate: the reference divides by zero (SIGFPE) here
     const double rcp = 1.0 / (double)d;
     const uint32_t hi = (uint32_t)(s >> 32), lo = (uint32_t)s;
     uint32_t q1 = (uint32_t)((double)hi * rcp);
@@ -107,17 +108,17 @@ __global__ __launch_bounds__(256) void sample_kernel(SamplerArgs a) {
             const int4 g = a.grp[i];
             if (keep_head) {  // corrupt_head(h, r): new TAIL outside tails(h,r)
                 long long tmp = (long long)mod_u64_u32(s, (uint32_t)(a.ent_total - g.y));
-                ot = filtered_pick(a.tails_hr + g.x, g.y, tmp);
+                ot = min(filtered_pick(a.tails_hr + g.x, g.y, tmp), a.ent_total - 1);   // (clamp: only reachable in that degenerate case)
             } else {          // corrupt_tail(t, r): new HEAD outside heads(t,r)
                 long long tmp = (long long)mod_u64_u32(s, (uint32_t)(a.ent_total - g.w));
-                oh = filtered_pick(a.heads_tr + g.z, g.w, tmp);
+                oh = min(filtered_pick(a.heads_tr + g.z, g.w, tmp), a.ent_total - 1);
             }
         } else if (k > a.neg) {  // Base.cpp:133-139: corrupt_rel(h, t)
             s = lcg_skip(s, 2ull * a.neg + (unsigned long long)(k - 1 - a.neg));
             s = lcg_step(s);
             const int2 g = a.ht[i];
             long long tmp = (long long)mod_u64_u32(s, (uint32_t)(a.rel_total - g.y));
-            orr = filtered_pick(a.rels_ht + g.x, g.y, tmp);
+            orr = min(filtered_pick(a.rels_ht + g.x, g.y, tmp), a.rel_total - 1);
         }
         const long long o = b + k * a.out_stride;
         a.out_h[o] = oh; a.out_t[o] = ot; a.out_r[o] = orr;

@@ -528,3 +528,15 @@ def test_tiny_batches_match_oracle(model, B, n, grad_path):
         for k in g_o:
             upd = (before[k] - after[k]) / con.alpha
             assert np.abs(upd - g_o[k]).max() <= 1e-4 * (np.abs(g_o[k]).max() + 1e-30), k
+
+
+def test_out_of_range_ids_are_rejected_on_the_host():
+    from openkeonspark_amd import KgeError
+    con = make_engine("transe", 20, 3, 16, 1, 0)
+    ok = np.array([0, 1]), np.array([2, 3]), np.array([0, 0])
+    con.test_step(*ok)
+    for bad in ((np.array([0, 20]), ok[1], ok[2]), (ok[0], np.array([2, -1]), ok[2]), (ok[0], ok[1], np.array([0, 3]))):
+        with pytest.raises(KgeError):
+            con.test_step(*bad)
+        with pytest.raises(KgeError):
+            con.train_step(bad[0], bad[1], bad[2], None)
