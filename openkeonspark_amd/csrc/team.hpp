@@ -22,13 +22,17 @@ __device__ __forceinline__ float team_sum(float v) {
     v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1] : lane ^ 2
     v += dpp_f<0x124>(v);  // row_ror:4  (rotations keep the 16-lane row sum uniform)
     v += dpp_f<0x128>(v);  // row_ror:8
-    if constexpr (L >= 32) {
+    if constexpr (L == 32) {
         // ds_swizzle bit mode: and=0x1F, or=0, xor=0x10 -> lane ^ 16 inside each 32-lane half
         v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (0x10 << 10) | 0x1F));
     }
     if constexpr (L == 64) {
-        v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
-            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+        // wave-wide: row_bcast:15 adds row 0's sum into row 1 and row 2's into row 3, row_bcast:31 adds lane 31 (rows 0+1)
+        // into rows 2,3; lane 63 then holds the total.  All DPP: no ds_swizzle (an LDS-path op with an lgkmcnt wait in
+        // the middle of every reduction), one v_readlane instead of two.
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+        v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
     }
     return v;
 }
