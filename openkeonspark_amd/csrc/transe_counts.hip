@@ -284,36 +284,32 @@ __global__ __launch_bounds__(256) void bkt_hist_kernel(const int32_t *__restrict
         if (hist[i]) atomicAdd(&bucket_total[i], hist[i]);
 }
 
-// exclusive scan of the NB+1 bucket totals -> bucket_start[0..NB+1]; cursors start there; totals re-zeroed
-__global__ __launch_bounds__(1024) void bkt_scan_kernel(int32_t *__restrict__ bucket_total, int32_t *__restrict__ bucket_start,
-                                                        int32_t *__restrict__ cursor) {
-    __shared__ int buf[1024];
-    const int t = threadIdx.x;
-    const int v = t <= NB ? bucket_total[t] : 0;
-    buf[t] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
-        const int add = t >= off ? buf[t - off] : 0;
-        __syncthreads();
-        buf[t] += add;
-        __syncthreads();
-    }
-    if (t <= NB) {
-        const int excl = buf[t] - v;
-        bucket_start[t] = excl;
-        cursor[t] = excl;
-        bucket_total[t] = 0;
-        if (t == NB) bucket_start[NB + 1] = buf[t];
-    }
-}
-
 // (record id, destination row) pairs grouped by bucket; the order inside a bucket is arbitrary
-__global__ __launch_bounds__(256) void bkt_scatter_kernel(const int32_t *__restrict__ dst, int M, int rpb,
-                                                          int32_t *__restrict__ cursor, int2 *__restrict__ pairs) {
+// Every block first scans the NB+1 bucket totals itself (an exclusive scan of 513 ints in LDS is cheaper than the launch
+// of a scan kernel); block 0 publishes bucket_start[0..NB+1] for the kernels that follow.  Cursors count from 0 inside
+// each bucket; cursors and totals are re-zeroed by bkt_sort_kernel.
+__global__ __launch_bounds__(256) void bkt_scatter_kernel(const int32_t *__restrict__ dst, int M, int rpb, const int32_t *__restrict__ bucket_total,
+                                                          int32_t *__restrict__ bucket_start, int32_t *__restrict__ cursor,
+                                                          int2 *__restrict__ pairs) {
     __shared__ int hist[NB + 1];
     __shared__ int base_of[NB + 1];
+    __shared__ int scan[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) scan[i] = i <= NB ? bucket_total[i] : 0;
     for (int i = threadIdx.x; i <= NB; i += 256) hist[i] = 0;
     __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan, 4 elements per thread
+        int add[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int i = threadIdx.x + 256 * k; add[k] = i >= off ? scan[i - off] : 0; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) scan[threadIdx.x + 256 * k] += add[k];
+        __syncthreads();
+    }
+    // exclusive start of bucket i = scan[i - 1]
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i <= NB + 1; i += 256) bucket_start[i] = i ? scan[i - 1] : 0;
+    }
     const int base = blockIdx.x * BTILE;
     int d[BTILE / 256];
 #pragma unroll
@@ -325,7 +321,7 @@ __global__ __launch_bounds__(256) void bkt_scatter_kernel(const int32_t *__restr
     __syncthreads();
     for (int i = threadIdx.x; i <= NB; i += 256) {
         const int c = hist[i];
-        base_of[i] = c ? atomicAdd(&cursor[i], c) : 0;   // reserve this tile's range in bucket i
+        base_of[i] = c ? (i ? scan[i - 1] : 0) + atomicAdd(&cursor[i], c) : 0;   // reserve this tile's range in bucket i
         hist[i] = 0;
     }
     __syncthreads();
@@ -346,10 +342,15 @@ __global__ __launch_bounds__(256) void bkt_scatter_kernel(const int32_t *__restr
 // atomic rate -- 3.8 M wave-level ds_add per step -- at 230 us; registers + sorted runs take ~60.)
 __global__ __launch_bounds__(256) void bkt_sort_kernel(const int2 *__restrict__ pairs, const int32_t *__restrict__ bucket_start,
                                                        int rpb, int rows, int32_t *__restrict__ out_keys,
-                                                       int32_t *__restrict__ out_ids) {
+                                                       int32_t *__restrict__ out_ids, int32_t *__restrict__ bucket_total,
+                                                       int32_t *__restrict__ cursor) {
     extern __shared__ int lds_h[];   // [rpb] histogram, then running offsets
     const int b = blockIdx.x;
     const int row0 = b * rpb;
+    if (threadIdx.x == 0) {   // totals and cursors back to zero for the next step (block 0 also the trash bucket's)
+        bucket_total[b] = 0; cursor[b] = 0;
+        if (b == 0) { bucket_total[NB] = 0; cursor[NB] = 0; }
+    }
     if (row0 >= rows) return;
     const int start = bucket_start[b], end = bucket_start[b + 1];
     for (int i = threadIdx.x; i < rpb; i += 256) lds_h[i] = 0;
@@ -521,10 +522,9 @@ int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t 
         int32_t *totals = g_c.tile_hist, *cursor = g_c.tile_hist + (NB + 2);
         int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
         hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals);
-        hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(1024), 0, stream, totals, g_c.bucket_start, cursor);
-        hipLaunchKernelGGL(bkt_scatter_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, cursor, pairs);
+        hipLaunchKernelGGL(bkt_scatter_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals, g_c.bucket_start, cursor, pairs);
         hipLaunchKernelGGL(bkt_sort_kernel, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
-                           g_c.dst_sorted, g_c.ids_sorted);
+                           g_c.dst_sorted, g_c.ids_sorted, totals, cursor);
         n_valid_p = g_c.bucket_start + NB;
     } else {
         int blocks = (int)((M + 255) / 256);
@@ -715,10 +715,9 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
         int32_t *totals = g_c.tile_hist, *cursor = g_c.tile_hist + (NB + 2);
         int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
         hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals);
-        hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(1024), 0, stream, totals, g_c.bucket_start, cursor);
-        hipLaunchKernelGGL(bkt_scatter_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, cursor, pairs);
+        hipLaunchKernelGGL(bkt_scatter_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals, g_c.bucket_start, cursor, pairs);
         hipLaunchKernelGGL(bkt_sort_kernel, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
-                           g_c.dst_sorted, g_c.ids_sorted);
+                           g_c.dst_sorted, g_c.ids_sorted, totals, cursor);
         const int32_t *n_valid_p = g_c.bucket_start + NB;   // start of the trash bucket == number of live records
 #define KGE_SEG2(LL, CC)                                                                                              \
     {                                                                                                                 \
