@@ -226,9 +226,13 @@ def main_fun(argv):
     rank = int(os.environ.get("RANK", "0"))
     if distributed:
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("KGE_SINGLE_DEVICE") == "1":
+            local_rank = 0        # rehearsal of the multi-rank path on a one-GPU box (with KGE_DIST_BACKEND=gloo)
+        torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        if not dist.is_initialized():
+            dist.init_process_group(os.environ.get("KGE_DIST_BACKEND", "nccl"))   # "nccl" is RCCL on ROCm
     con = get_conf(argv)
     con.device = "cuda:%d" % torch.cuda.current_device()
     con.set_model_and_session(con.model)

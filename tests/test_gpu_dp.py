@@ -167,3 +167,49 @@ def test_rank_with_an_empty_slice(tmp_path, sparse):
             continue
         assert np.array_equal(r0[k], r1[k]), k
         assert np.array_equal(r0[k], one[k]), k
+
+
+def _driver_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": str(rank), "KGE_SINGLE_DEVICE": "1", "KGE_DIST_BACKEND": "gloo",
+                       "KGE_COUNTS_MIN_RECORDS": "0"})
+    import torch.distributed as dist
+    from openkeonspark_amd import distribute_training as dt
+    out = os.path.join(out_dir, "run_w%d" % world)
+    args = ["--input_path", os.path.join(GOLDEN, "kg_small"), "--output_path", out, "--embedding_dimension", "32",
+            "--n_mini_batches", "4", "--ent_neg_rate", "2", "--alpha", "0.01", "--optimizer", "SGD", "--bern_flag", "1",
+            "--train_times", "3", "--work_threads", "4"]
+    con = dt.main_fun(dt.parse_args(args))
+    np.savez(os.path.join(out_dir, "drv_w%d_r%d.npz" % (world, rank)), step=con.global_step, **con.get_parameters())
+    met = dt.main_fun(dt.parse_args(args + ["--mode", "test"]))
+    import json
+    json.dump(met, open(os.path.join(out_dir, "drvlp_w%d_r%d.json" % (world, rank)), "w"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_cli_driver_under_two_ranks(tmp_path):
+    """distribute_training.main_fun launched as two torchrun-style ranks: same parameters as one process, one checkpoint
+    per epoch written by rank 0 only, and the test mode's link prediction split over the ranks."""
+    import json
+    import torch.multiprocessing as mp
+    port = 30300 + os.getpid() % 1000
+    mp.start_processes(_driver_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True, start_method="spawn")
+    mp.start_processes(_driver_worker, args=(2, port + 1, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    one = np.load(str(tmp_path / "drv_w1_r0.npz"))
+    r0 = np.load(str(tmp_path / "drv_w2_r0.npz"))
+    r1 = np.load(str(tmp_path / "drv_w2_r1.npz"))
+    assert int(one["step"]) == int(r0["step"]) == int(r1["step"]) == 12
+    for k in one.files:
+        assert np.array_equal(r0[k], r1[k]), k
+        assert np.array_equal(r0[k], one[k]), k
+    ck1 = sorted(f for f in os.listdir(str(tmp_path / "run_w1")) if f.startswith("model.ckpt"))
+    ck2 = sorted(f for f in os.listdir(str(tmp_path / "run_w2")) if f.startswith("model.ckpt"))
+    assert ck1 == ck2 and len(ck1) >= 1
+    m1 = json.load(open(str(tmp_path / "drvlp_w1_r0.json")))
+    m2 = json.load(open(str(tmp_path / "drvlp_w2_r1.json")))
+    assert m1.keys() == m2.keys()
+    for k in m1:
+        assert abs(m1[k] - m2[k]) <= 1e-12 * max(1.0, abs(m1[k])), k
