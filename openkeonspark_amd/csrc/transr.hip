@@ -489,13 +489,13 @@ __global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // t
 
 // wgrad v2 (dims 196..208, multiples of 4: the full 13 x 13 output tile grid): g_M[r][i][j] += sum over rows of
 // ent[e_row][i] * GP[slot_row][j].  A workgroup owns SPAN2 consecutive 128-row tiles of the relation-sorted job list
-// (256 rows between flushes) and ALL output tiles, so the rows are streamed exactly once; wave w takes output row-tiles
+// (512 rows between flushes) and ALL output tiles, so the rows are streamed exactly once; wave w takes output row-tiles
 // w, w+4, w+8 with every column tile, and the 13th row-tile's column tiles w, w+4, w+8, w+12 (43 / 42 of the 169 tiles
 // per wave; the 4th extra tile of waves 1..3 does not exist: it is computed on a clamped column and dropped at the flush,
 // which keeps the MFMA block branch-free).  Rows are staged 32 at a time, the next 32 in flight during the MFMA loop.
 // A relation whose whole bucket lies inside the span has one owner: its matrix gradient is stored, not added with
 // atomics (the accumulator is zero).
-constexpr int SPAN2 = 2;
+constexpr int SPAN2 = 4;
 constexpr int WK2 = 32;                 // rows per staged chunk (8 k-steps)
 constexpr int WI2 = 3;                  // full output row-tiles per wave (row tiles 0..11)
 constexpr int WX2 = 4;                  // column tiles of row tile 12 per wave
