@@ -307,8 +307,19 @@ __device__ __forceinline__ bool standalone_negative(const Team<L, C> &tm, const 
     return true;
 }
 
+template <int MODEL, int L, int C, bool REC>
+__device__ __forceinline__ void fwdbwd_body(const FbArgs &a);
+
 template <int MODEL, int L, int C, bool REC = false>
-__global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) {
+__global__ __launch_bounds__(256) void fwdbwd_kernel(FbArgs a) { fwdbwd_body<MODEL, L, C, REC>(a); }
+
+// the same body compiled for four waves per SIMD (<= 128 VGPRs): the projecting models at C <= 4 are latency-bound on
+// their reduction chains, and a fourth resident wave hides more of it than the registers it gives up cost
+template <int MODEL, int L, int C, bool REC = false>
+__global__ __launch_bounds__(256, 4) void fwdbwd_kernel_occ4(FbArgs a) { fwdbwd_body<MODEL, L, C, REC>(a); }
+
+template <int MODEL, int L, int C, bool REC>
+__device__ __forceinline__ void fwdbwd_body(const FbArgs &a) {
     constexpr int TEAMS = 256 / L;
     using RS = RecSlots<MODEL>;
     __shared__ float red[TEAMS];
@@ -1016,7 +1027,10 @@ static void launch_fb(const FbArgs &a, float *d_loss, hipStream_t stream) {
     if (blocks < 1) blocks = 1;
     FbArgs f = a;
     f.loss_out = d_loss; f.loss_ticket = engine().dev.loss_ticket;   // the last block writes the loss
-    hipLaunchKernelGGL((fwdbwd_kernel<MODEL, L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
+    if constexpr (MODEL != KGE_TRANSE && C <= 4)
+        hipLaunchKernelGGL((fwdbwd_kernel_occ4<MODEL, L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
+    else
+        hipLaunchKernelGGL((fwdbwd_kernel<MODEL, L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
 }
 
 template <int MODEL, int L, int C>
@@ -1027,7 +1041,10 @@ static void launch_fb_records(const FbArgs &a, float *d_loss, hipStream_t stream
     if (blocks < 1) blocks = 1;
     FbArgs f = a;
     f.loss_out = d_loss; f.loss_ticket = engine().dev.loss_ticket;
-    hipLaunchKernelGGL((fwdbwd_kernel<MODEL, L, C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
+    if constexpr ((MODEL == KGE_TRANSH || MODEL == KGE_TRANSD) && C <= 4)
+        hipLaunchKernelGGL((fwdbwd_kernel_occ4<MODEL, L, C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
+    else
+        hipLaunchKernelGGL((fwdbwd_kernel<MODEL, L, C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
 }
 
 template <int MODEL>
