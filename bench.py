@@ -90,7 +90,6 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel-reps", type=int, default=20)
     args = ap.parse_args()
 
     import numpy as np
@@ -169,35 +168,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import ctypes
     for _ in range(args.warmup):
         con.train_step(sync=False)
     sync()
+    # roofline of the dominant kernel (TransE emit): one HIP event pair per launch, recorded on the kernel's launch stream
+    # INSIDE the timed region and read back after it (no synchronisation between the steps)
+    con.lib.kge_set_option(b"time_emit", 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         con.train_step(sync=False)
     sync()
     dt = time.perf_counter() - t0
+    con.lib.kge_set_option(b"time_emit", 0)
     if use_dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(con._loss.item())
-
-    # ---- roofline of the dominant kernel (TransE emit), HIP events around THAT kernel on its launch stream
-    import ctypes
-    dev, n_pos = con.sample_device()
-    torch.cuda.synchronize()
-    con.lib.kge_set_option(b"time_emit", 1)
-    kern = []
-    for i in range(args.kernel_reps):
-        con.forward_counts(dev, n_pos, max(n_local, 1), B * NEG)
-        ms = ctypes.c_float()
-        con.lib.kge_last_kernel_ms(b"transe_emit", ctypes.byref(ms))
-        kern.append(ms.value)
-        con._counts.zero_()
-    con.lib.kge_set_option(b"time_emit", 0)
-    torch.cuda.synchronize()
-    kern_ms = sum(kern) / len(kern)
+    ms = ctypes.c_float()
+    timed = ctypes.c_int64()
+    from openkeonspark_amd import _lib as _l
+    _l.check(con.lib.kge_kernel_ms_mean(b"transe_emit", ctypes.byref(ms), ctypes.byref(timed)), con.lib)
+    kern_ms = float(ms.value)
+    n_pos = n_local
     alg_bytes = algorithmic_bytes_per_positive(NEG, DIM) * n_pos
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic = None
@@ -225,7 +219,8 @@ def main():
                        "parallelism": "dp%d" % world, "final_loss": loss},
             "roofline": {"bound": "hbm", "kernel": "kge::transe_emit_vec_kernel<64,1,4,1,true>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "traffic": traffic, "kernel_ms": kern_ms, "kernel_launches_timed": int(timed.value),
+                         "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(fb_dir)

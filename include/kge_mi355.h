@@ -128,6 +128,9 @@ const char *kge_version(void);
 int kge_set_option(const char *name, INT value);
 /* elapsed time of the most recent launch of a timed kernel; name = "transe_emit" (needs time_emit) */
 int kge_last_kernel_ms(const char *name, float *ms);
+/* mean over the launches since "time_emit" was switched on (the most recent 512 of them); one event pair per launch, read
+ * back here, so nothing synchronises inside the timed region */
+int kge_kernel_ms_mean(const char *name, float *mean_ms, INT *launches);
 
 /* Same as importTrainFiles but from arrays already in memory (h,t,r in FILE ORDER, duplicates
  * kept; new_batch_total as batch2id.txt's first line, 0 = not incremental).  Restates

@@ -59,6 +59,7 @@ def _declare(L):
     L.kge_import_train_arrays.argtypes = [i64, i64, i64, vp, vp, vp, i64]
     L.kge_set_option.argtypes = [ctypes.c_char_p, i64]
     L.kge_last_kernel_ms.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)]
+    L.kge_kernel_ms_mean.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i64)]
     L.kge_index_copy.restype = i64
     L.kge_index_copy.argtypes = [ctypes.c_char_p, vp, i64]
     L.kge_get_stream_states.argtypes = [vp, i64]

@@ -224,7 +224,7 @@ int kge_set_option(const char *name, INT value) {
     if (n == "hub_copies") { engine().hub_copies = value != 0; return KGE_OK; }
     if (n == "lp_v1") { engine().lp_v1 = value != 0; return KGE_OK; }
     if (n == "transr_v1") { engine().transr_v1 = (int)value; return KGE_OK; }
-    if (n == "time_emit") { engine().time_emit = value != 0; return KGE_OK; }
+    if (n == "time_emit") { engine().time_emit = value != 0; if (value) engine().emit_launches = 0; return KGE_OK; }
     if (n == "libc_rand_restart") { engine().libc = LibcRand(); return KGE_OK; }  // as in a fresh process
     return fail(KGE_ERR_BAD_ARG, "kge_set_option: unknown option " + n);
 }
@@ -233,9 +233,29 @@ int kge_last_kernel_ms(const char *name, float *ms) {
     Engine &e = engine();
     std::string n = name ? name : "";
     if (n != "transe_emit" || !ms) return fail(KGE_ERR_BAD_ARG, "kge_last_kernel_ms: unknown kernel " + n);
-    if (!e.ev_emit0) return fail(KGE_ERR_BAD_ARG, "kge_last_kernel_ms: enable option time_emit and run a step first");
-    if (hip_check(hipEventSynchronize(e.ev_emit1), "event sync")) return KGE_ERR_NO_DEVICE;
-    return hip_check(hipEventElapsedTime(ms, e.ev_emit0, e.ev_emit1), "event elapsed");
+    if (e.emit_launches <= 0) return fail(KGE_ERR_BAD_ARG, "kge_last_kernel_ms: enable option time_emit and run a step first");
+    const int slot = (int)((e.emit_launches - 1) % Engine::kEmitRing);
+    if (hip_check(hipEventSynchronize(e.ev_emit1[slot]), "event sync")) return KGE_ERR_NO_DEVICE;
+    return hip_check(hipEventElapsedTime(ms, e.ev_emit0[slot], e.ev_emit1[slot]), "event elapsed");
+}
+
+int kge_kernel_ms_mean(const char *name, float *mean_ms, INT *launches) {
+    Engine &e = engine();
+    std::string n = name ? name : "";
+    if (n != "transe_emit" || !mean_ms) return fail(KGE_ERR_BAD_ARG, "kge_kernel_ms_mean: unknown kernel " + n);
+    const long long have = e.emit_launches < Engine::kEmitRing ? e.emit_launches : (long long)Engine::kEmitRing;
+    if (have <= 0) return fail(KGE_ERR_BAD_ARG, "kge_kernel_ms_mean: enable option time_emit and run steps first");
+    double sum = 0.0;
+    for (long long i = 0; i < have; i++) {
+        const int slot = (int)((e.emit_launches - 1 - i) % Engine::kEmitRing);
+        float ms = 0.f;
+        if (hip_check(hipEventSynchronize(e.ev_emit1[slot]), "event sync")) return KGE_ERR_NO_DEVICE;
+        if (hip_check(hipEventElapsedTime(&ms, e.ev_emit0[slot], e.ev_emit1[slot]), "event elapsed")) return KGE_ERR_NO_DEVICE;
+        sum += ms;
+    }
+    *mean_ms = (float)(sum / (double)have);
+    if (launches) *launches = have;
+    return KGE_OK;
 }
 
 int kge_import_train_arrays(INT ent_total, INT rel_total, INT n, const INT *h, const INT *t, const INT *r,

@@ -914,13 +914,14 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
                                (long long)a.rel_total, a.D, const_cast<float *>(a.inv_norm));
         }
         Engine &eng = engine();
+        const int slot = (int)(eng.emit_launches % Engine::kEmitRing);
         if (eng.time_emit) {   // HIP events around THE kernel, on its launch stream (bench.py roofline)
-            if (!eng.ev_emit0) { (void)hipEventCreate(&eng.ev_emit0); (void)hipEventCreate(&eng.ev_emit1); }
-            (void)hipEventRecord(eng.ev_emit0, stream);
+            if (!eng.ev_emit0[slot]) { (void)hipEventCreate(&eng.ev_emit0[slot]); (void)hipEventCreate(&eng.ev_emit1[slot]); }
+            (void)hipEventRecord(eng.ev_emit0[slot], stream);
         }
         if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        if (eng.time_emit) (void)hipEventRecord(eng.ev_emit1, stream);
+        if (eng.time_emit) { (void)hipEventRecord(eng.ev_emit1[slot], stream); eng.emit_launches++; }
     } else
         hipLaunchKernelGGL((transe_emit_kernel<L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
     // groups with non sampler-shaped negatives: exact fp32 path into the residual accumulators
