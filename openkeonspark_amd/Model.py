@@ -51,6 +51,46 @@ class Model(object):
     def get_config(self):
         return self.config
 
+    # --- batch views (Model.py:10-53).  The reference slices TF placeholders; here they are views of the batch the
+    # config currently holds (Config.batch_h/t/r/y as filled by sampling(), layout [B positives | B negs round k ...]):
+    # in_batch=True gives the (B, 1) / (B, n) shapes of Model.py:62-69, negative k of positive b at [b, k].
+    def _batch(self, name):
+        arr = getattr(self, name, None)
+        return arr if arr is not None else getattr(self.config, name)
+
+    def _split(self, arr, in_batch, positive):
+        B = self.config.batch_size
+        if positive:
+            return arr[0:B].reshape(1, -1).T if in_batch else arr[0:B]
+        rest = arr[B:self.config.batch_seq_size]
+        n = self.config.negative_ent + self.config.negative_rel
+        return rest.reshape(n, -1).T if in_batch else rest
+
+    def get_positive_instance(self, in_batch=True):
+        return [self._split(self._batch(k), in_batch, True) for k in ("batch_h", "batch_t", "batch_r")]
+
+    def get_negative_instance(self, in_batch=True):
+        return [self._split(self._batch(k), in_batch, False) for k in ("batch_h", "batch_t", "batch_r")]
+
+    def get_positive_labels(self, in_batch=True):
+        return self._split(self._batch("batch_y"), in_batch, True)
+
+    def get_negative_labels(self, in_batch=True):
+        return self._split(self._batch("batch_y"), in_batch, False)
+
+    def get_all_instance(self, in_batch=False):
+        n = 1 + self.config.negative_ent + self.config.negative_rel
+        arrs = [self._batch(k) for k in ("batch_h", "batch_t", "batch_r")]
+        return [a.reshape(n, -1).T for a in arrs] if in_batch else arrs
+
+    def get_all_labels(self, in_batch=False):
+        n = 1 + self.config.negative_ent + self.config.negative_rel
+        y = self._batch("batch_y")
+        return y.reshape(n, -1).T if in_batch else y
+
+    def get_predict_instance(self):
+        return [self.predict_h, self.predict_t, self.predict_r]
+
     # --- Model.py:55-74 -------------------------------------------------------------------------
     def input_def(self):
         config = self.config

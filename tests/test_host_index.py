@@ -137,3 +137,32 @@ def test_slice_positions_tile_the_batch():
                     assert n == 0 or f == tot
                     tot += n
                 assert tot == B
+
+
+def test_model_batch_views_follow_the_reference_layout():
+    """Model.get_*_instance / labels (Model.py:10-53): negative k of positive b sits at B*(k+1)+b in the flat batch and at
+    [b, k] of the in-batch view."""
+    from openkeonspark_amd.Model import Model
+
+    class Cfg:
+        batch_size, negative_ent, negative_rel = 4, 2, 1
+        batch_seq_size = 4 * (1 + 2 + 1)
+        batch_h = np.arange(16) * 10
+        batch_t = np.arange(16) * 10 + 1
+        batch_r = np.arange(16) * 10 + 2
+        batch_y = np.where(np.arange(16) < 4, 1.0, -1.0).astype(np.float32)
+
+    m = Model.__new__(Model)
+    m.config = Cfg
+    ph, pt, pr = m.get_positive_instance()
+    assert ph.shape == (4, 1) and ph[:, 0].tolist() == [0, 10, 20, 30] and pr[2, 0] == 22
+    nh, nt, nr = m.get_negative_instance()
+    assert nh.shape == (4, 3)
+    for b in range(4):
+        for k in range(3):
+            assert nh[b, k] == Cfg.batch_h[4 * (k + 1) + b] and nt[b, k] == Cfg.batch_t[4 * (k + 1) + b]
+    assert m.get_negative_instance(in_batch=False)[0].tolist() == Cfg.batch_h[4:].tolist()
+    assert m.get_positive_labels().ravel().tolist() == [1.0] * 4 and (m.get_negative_labels() == -1).all()
+    ah, _, _ = m.get_all_instance(in_batch=True)
+    assert ah.shape == (4, 4) and ah[1].tolist() == [10, 50, 90, 130]
+    assert m.get_all_labels().shape == (16,) and m.get_all_instance()[2] is Cfg.batch_r
