@@ -122,7 +122,7 @@ const char *kge_version(void);
  *                        atomics serialise); 0 = straight into the accumulators
  *   "transr_v1":         1 = TransR always on the 32x32x2 MFMA tiles, 2 = 16x16x4 tiles with the all-output-tiles
  *                        wgrad forced (test hooks; default 0 = automatic)
- *   "time_emit":         1 = bracket the TransE emit kernel with HIP events on its launch stream
+ *   "time_emit":         N > 0 = bracket every N-th launch of the TransE emit kernel with HIP events on its launch stream
  *   "libc_rand_restart": restart the glibc-compatible seed generator, as in a fresh process (the next
  *                        randReset then yields 1804289383, 846930886, ... again) */
 int kge_set_option(const char *name, INT value);

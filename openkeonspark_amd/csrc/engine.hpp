@@ -48,10 +48,11 @@ struct Engine {
     DeviceIndex dev;
     std::string last_error;
     int device_state = 0;  // 0 unknown, 1 ok, -1 none
-    int time_emit = 0;          // record HIP events around the TransE emit kernel (kge_last_kernel_ms)
+    int time_emit = 0;          // N > 0: record HIP events around every N-th launch of the TransE emit kernel (kge_last_kernel_ms / kge_kernel_ms_mean)
     static constexpr int kEmitRing = 512;   // event pairs: the timed launches of a bench run are read back AFTER the run, no sync inside it
     hipEvent_t ev_emit0[kEmitRing] = {}, ev_emit1[kEmitRing] = {};
     long long emit_launches = 0;   // timed launches since time_emit was switched on
+    long long emit_seen = 0;       // all launches since then (time_emit = N times every N-th)
     int64_t inv_table_max_bytes = int64_t(256) << 20;  // TransE emit: per-row inverse-norm table only while the tables are this small
     int float_records = 1;              // TransH / TransD (and TransE without counts): record + segmented-sum path instead of fp32 atomics
     int64_t float_records_min = 1 << 16; // ... from this many gradient rows per step (below it the atomic kernel alone is quicker)

@@ -915,13 +915,14 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
         }
         Engine &eng = engine();
         const int slot = (int)(eng.emit_launches % Engine::kEmitRing);
-        if (eng.time_emit) {   // HIP events around THE kernel, on its launch stream (bench.py roofline)
+        const bool timed = eng.time_emit > 0 && (eng.emit_seen++ % eng.time_emit) == 0;   // every time_emit-th launch
+        if (timed) {   // HIP events around THE kernel, on its launch stream (bench.py roofline)
             if (!eng.ev_emit0[slot]) { (void)hipEventCreate(&eng.ev_emit0[slot]); (void)hipEventCreate(&eng.ev_emit1[slot]); }
             (void)hipEventRecord(eng.ev_emit0[slot], stream);
         }
         if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        if (eng.time_emit) { (void)hipEventRecord(eng.ev_emit1[slot], stream); eng.emit_launches++; }
+        if (timed) { (void)hipEventRecord(eng.ev_emit1[slot], stream); eng.emit_launches++; }
     } else
         hipLaunchKernelGGL((transe_emit_kernel<L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
     // groups with non sampler-shaped negatives: exact fp32 path into the residual accumulators
