@@ -489,49 +489,57 @@ __global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // t
 
 // wgrad v2 (dims 196..208, multiples of 4: the full 13 x 13 output tile grid): g_M[r][i][j] += sum over rows of
 // ent[e_row][i] * GP[slot_row][j].  A workgroup owns SPAN2 consecutive 128-row tiles of the relation-sorted job list
-// (512 rows between flushes) and ALL output tiles, so the rows are streamed exactly once; wave w takes output row-tiles
-// w, w+4, w+8 with every column tile, and the 13th row-tile's column tiles w, w+4, w+8, w+12 (43 / 42 of the 169 tiles
-// per wave; the 4th extra tile of waves 1..3 does not exist: it is computed on a clamped column and dropped at the flush,
-// which keeps the MFMA block branch-free).  Rows are staged 32 at a time, the next 32 in flight during the MFMA loop.
-// A relation whose whole bucket lies inside the span has one owner: its matrix gradient is stored, not added with
+// (512 rows between flushes) and one HALF of the output row tiles (blockIdx.y: tiles 0..6 / 7..12) with every column
+// tile: 2 x 13 accumulator tiles per wave (104 registers), which leaves room for two workgroups per CU -- with all
+// 169 tiles in one workgroup (172 + staging registers, one workgroup per CU) 63 % of the wave cycles were parked on
+// s_waitcnt.  Wave w takes local row tiles w and w+4 (the 8th does not exist: computed on a clamped tile, dropped at the
+// flush, which keeps the MFMA block branch-free).  Rows are staged 16 at a time, the next 16 in flight during the MFMA
+// loop.  A relation whose whole bucket lies inside the span has one owner: its matrix gradient is stored, not added with
 // atomics (the accumulator is zero).
 constexpr int SPAN2 = 4;
-constexpr int WK2 = 32;                 // rows per staged chunk (8 k-steps)
-constexpr int WI2 = 3;                  // full output row-tiles per wave (row tiles 0..11)
-constexpr int WX2 = 4;                  // column tiles of row tile 12 per wave
+constexpr int WK2 = 16;                 // rows per staged chunk (4 k-steps)
+constexpr int WH2 = 7;                  // output row tiles per half
+constexpr int LDX2 = WH2 * 16;          // [row k][i] stride of the staged X half: 112 = 16 mod 32 banks
 
-__global__ __launch_bounds__(256) void wgrad2_kernel(GemmArgs a, float *__restrict__ g_mat) {
+__global__ __launch_bounds__(256, 2) void wgrad2_kernel(GemmArgs a, float *__restrict__ g_mat) {
     const int n_tiles = a.n_tiles[0];
     const int t0 = blockIdx.x * SPAN2;
     if (t0 >= n_tiles) return;
     const int t1 = min(t0 + SPAN2, n_tiles);
-    __shared__ __attribute__((aligned(16))) float Xs[WK2 * LDB2];    // [row k][i], stride 208
-    __shared__ __attribute__((aligned(16))) float Gs[WK2 * LDB2];    // [row k][j]
+    __shared__ __attribute__((aligned(16))) float Xs[WK2 * LDX2];    // [row k][i - i0]
+    __shared__ __attribute__((aligned(16))) float Gs[WK2 * LDB2];    // [row k][j], stride 208
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    f32x4 acc[WI2][NT2], accx[WX2];
+    const int half = blockIdx.y;
+    const int i0 = half * LDX2;                                       // first output row (= X column) of this half
+    const int n_it = half == 0 ? WH2 : NT2 - WH2;                     // row tiles that exist in this half (7 / 6)
+    f32x4 acc[2][NT2];
 #pragma unroll
-    for (int s2 = 0; s2 < WI2; s2++)
+    for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
         for (int t2 = 0; t2 < NT2; t2++) acc[s2][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int x2 = 0; x2 < WX2; x2++) accx[x2] = f32x4{0.f, 0.f, 0.f, 0.f};
     // rows [span_lo, span_hi) of the sorted job list belong to this workgroup
     const int span_lo = a.tile_row0[t0];
     const int span_hi = a.tile_row0[t1 - 1] + min(RW2, a.bucket_start[a.tile_rel[t1 - 1] + 1] - a.tile_row0[t1 - 1]);
-    constexpr int Q = LDB2 / 4;                       // float4 per staged row (52)
-    constexpr int NL = (WK2 * Q + 255) / 256;         // float4 loads per thread and operand (7)
-    float4 rx[NL], rg[NL];
-    const int qx = a.De / 4, qg = a.Dr / 4;           // valid float4 per row
+    constexpr int QX = LDX2 / 4, QG = LDB2 / 4;       // float4 per staged row: 28 of X, 52 of GP
+    constexpr int NX = (WK2 * QX + 255) / 256;        // float4 loads per thread: 2 of X
+    constexpr int NG = (WK2 * QG + 255) / 256;        //                          4 of GP
+    float4 rx[NX], rg[NG];
+    const int qx = (min(a.De, i0 + LDX2) - i0) / 4, qg = a.Dr / 4;   // valid float4 per row
 #define KGE_WLOAD(row_first_, crow_)                                                                          \
     {                                                                                                         \
-        static_for<0, NL>([&](auto uc) {                                                                      \
+        static_for<0, NX>([&](auto uc) {                                                                      \
             constexpr int u = decltype(uc)::value;                                                            \
-            const int idx = min(tid + 256 * u, WK2 * Q - 1);                                                  \
-            const int kk = idx / Q, q = idx - kk * Q;                                                         \
+            const int idx = min(tid + 256 * u, WK2 * QX - 1);                                                 \
+            const int kk = idx / QX, q = idx - kk * QX;                                                       \
+            const int e = a.job_ent[a.sorted_slots[(row_first_) + min(kk, (crow_) - 1)]];                     \
+            rx[u] = *reinterpret_cast<const float4 *>(a.ent + (long long)e * a.De + i0 + 4 * min(q, qx - 1)); \
+        });                                                                                                   \
+        static_for<0, NG>([&](auto uc) {                                                                      \
+            constexpr int u = decltype(uc)::value;                                                            \
+            const int idx = min(tid + 256 * u, WK2 * QG - 1);                                                 \
+            const int kk = idx / QG, q = idx - kk * QG;                                                       \
             const int sl = a.sorted_slots[(row_first_) + min(kk, (crow_) - 1)];                               \
-            const int e = a.job_ent[sl];                                                                      \
-            rx[u] = *reinterpret_cast<const float4 *>(a.ent + (long long)e * a.De + 4 * min(q, qx - 1));      \
             rg[u] = *reinterpret_cast<const float4 *>(a.GP + (long long)sl * a.Dr + 4 * min(q, qg - 1));      \
         });                                                                                                   \
     }
@@ -545,26 +553,17 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(GemmArgs a, float *__restri
     {                                                                                                         \
         float *G = g_mat + (long long)(rel_) * a.De * a.Dr;                                                   \
         const bool sole = a.bucket_start[rel_] >= span_lo && a.bucket_start[(rel_) + 1] <= span_hi;           \
-        _Pragma("unroll") for (int s2 = 0; s2 < WI2; s2++) {                                                  \
+        _Pragma("unroll") for (int s2 = 0; s2 < 2; s2++) {                                                    \
             _Pragma("unroll") for (int t2 = 0; t2 < NT2; t2++) {                                              \
                 const int j = t2 * 16 + (lane & 15);                                                          \
-                _Pragma("unroll") for (int v = 0; v < 4; v++) {                                               \
-                    const int i = (wave + 4 * s2) * 16 + 4 * (lane >> 4) + v;                                 \
-                    KGE_WPUT(i, j, acc[s2][t2][v])                                                            \
+                if (wave + 4 * s2 < n_it) {                                                                   \
+                    _Pragma("unroll") for (int v = 0; v < 4; v++) {                                           \
+                        const int i = i0 + (wave + 4 * s2) * 16 + 4 * (lane >> 4) + v;                        \
+                        KGE_WPUT(i, j, acc[s2][t2][v])                                                        \
+                    }                                                                                         \
                 }                                                                                             \
                 acc[s2][t2] = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
             }                                                                                                 \
-        }                                                                                                     \
-        _Pragma("unroll") for (int x2 = 0; x2 < WX2; x2++) {                                                  \
-            const int jt = wave + 4 * x2;                                                                     \
-            if (jt < NT2) {                                                                                   \
-                const int j = jt * 16 + (lane & 15);                                                          \
-                _Pragma("unroll") for (int v = 0; v < 4; v++) {                                               \
-                    const int i = 12 * 16 + 4 * (lane >> 4) + v;                                              \
-                    KGE_WPUT(i, j, accx[x2][v])                                                               \
-                }                                                                                             \
-            }                                                                                                 \
-            accx[x2] = f32x4{0.f, 0.f, 0.f, 0.f};                                                             \
         }                                                                                                     \
     }
     int t = t0, c0 = 0;
@@ -584,12 +583,19 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(GemmArgs a, float *__restri
         first = false;
         {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            static_for<0, NL>([&](auto uc) {
+            static_for<0, NX>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 const int idx = tid + 256 * u;
-                if (idx < WK2 * Q) {
-                    const int kk = idx / Q, q = idx - kk * Q;
-                    *reinterpret_cast<float4 *>(&Xs[kk * LDB2 + 4 * q]) = (kk < crow && q < qx) ? rx[u] : z;
+                if (idx < WK2 * QX) {
+                    const int kk = idx / QX, q = idx - kk * QX;
+                    *reinterpret_cast<float4 *>(&Xs[kk * LDX2 + 4 * q]) = (kk < crow && q < qx) ? rx[u] : z;
+                }
+            });
+            static_for<0, NG>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int idx = tid + 256 * u;
+                if (idx < WK2 * QG) {
+                    const int kk = idx / QG, q = idx - kk * QG;
                     *reinterpret_cast<float4 *>(&Gs[kk * LDB2 + 4 * q]) = (kk < crow && q < qg) ? rg[u] : z;
                 }
             });
@@ -611,20 +617,14 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(GemmArgs a, float *__restri
 #pragma unroll
         for (int ks = 0; ks < WK2; ks += 4) {
             const int kk = ks + (lane >> 4);
-            float av[WI2];
+            float av[2];
 #pragma unroll
-            for (int s2 = 0; s2 < WI2; s2++) av[s2] = Xs[kk * LDB2 + (wave + 4 * s2) * 16 + (lane & 15)];   // A[i][k] = X[row k][i]
-            const float ax = Xs[kk * LDB2 + 12 * 16 + (lane & 15)];                                        // row tile 12
+            for (int s2 = 0; s2 < 2; s2++) av[s2] = Xs[kk * LDX2 + min(wave + 4 * s2, WH2 - 1) * 16 + (lane & 15)];   // A[i][k] = X[row k][i]
 #pragma unroll
             for (int t2 = 0; t2 < NT2; t2++) {
                 const float bv = Gs[kk * LDB2 + t2 * 16 + (lane & 15)];   // B[k][j] = GP[row k][j]
 #pragma unroll
-                for (int s2 = 0; s2 < WI2; s2++) acc[s2][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv, acc[s2][t2], 0, 0, 0);
-            }
-#pragma unroll
-            for (int x2 = 0; x2 < WX2; x2++) {
-                const float bv = Gs[kk * LDB2 + min(wave + 4 * x2, NT2 - 1) * 16 + (lane & 15)];
-                accx[x2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bv, accx[x2], 0, 0, 0);
+                for (int s2 = 0; s2 < 2; s2++) acc[s2][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv, acc[s2][t2], 0, 0, 0);
             }
         }
         if (!more) break;
@@ -678,7 +678,7 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
                                     m.negative_rel, d_loss, stream);
     if (rc) return rc;
     if (v2) {
-        const dim3 wg((max_tiles + SPAN2 - 1) / SPAN2, 1);
+        const dim3 wg((max_tiles + SPAN2 - 1) / SPAN2, 2);
         if (De <= 112) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 7>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
         else hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 13>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
         // the all-output-tiles wgrad (full 13 x 13 tile grid only) pays one 160 kB flush per relation change: only with
