@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SamplerArgs a) {
         s = lcg_step(s);  // Base.cpp:101-106: which training triple
         long long i = (long long)mod_magic(s, a.pick_div, a.pick_magic) + (a.new_batch > 0 ? a.train_dup - a.new_batch : 0);
         const int4 tr = a.pos[i];  // (h, t, r, -)
+        const int4 gq = a.grp[i];  // loaded together with it (not after the coin): one memory latency instead of two
         int oh = tr.x, ot = tr.y, orr = tr.z;
         if (k >= 1 && k <= a.neg) {
             s = lcg_skip(s, 2ull * (unsigned long long)(k - 1));
@@ -105,13 +106,12 @@ __global__ __launch_bounds__(256) void sample_kernel(SamplerArgs a) {
             const float prob = a.bern ? a.bern_prob[orr] : 500.0f;
             const bool keep_head = (float)(s % 1000ull) < prob;
             s = lcg_step(s);  // Corrupt.h:25: the one draw of the corruption
-            const int4 g = a.grp[i];
             if (keep_head) {  // corrupt_head(h, r): new TAIL outside tails(h,r)
-                long long tmp = (long long)mod_u64_u32(s, (uint32_t)(a.ent_total - g.y));
-                ot = min(filtered_pick(a.tails_hr + g.x, g.y, tmp), a.ent_total - 1);   // (clamp: only reachable in that degenerate case)
+                long long tmp = (long long)mod_u64_u32(s, (uint32_t)(a.ent_total - gq.y));
+                ot = min(filtered_pick(a.tails_hr + gq.x, gq.y, tmp), a.ent_total - 1);   // (clamp: only reachable in that degenerate case)
             } else {          // corrupt_tail(t, r): new HEAD outside heads(t,r)
-                long long tmp = (long long)mod_u64_u32(s, (uint32_t)(a.ent_total - g.w));
-                oh = min(filtered_pick(a.heads_tr + g.z, g.w, tmp), a.ent_total - 1);
+                long long tmp = (long long)mod_u64_u32(s, (uint32_t)(a.ent_total - gq.w));
+                oh = min(filtered_pick(a.heads_tr + gq.z, gq.w, tmp), a.ent_total - 1);
             }
         } else if (k > a.neg) {  // Base.cpp:133-139: corrupt_rel(h, t)
             s = lcg_skip(s, 2ull * a.neg + (unsigned long long)(k - 1 - a.neg));
