@@ -262,12 +262,13 @@ class Config(object):
         # all-gathered (the sparse touched-row exchange of BASELINE config #5).  SGD only: TF1's sparse Adam
         # sweeps every row of m, v and the table each step, which is the dense path by definition.
         table_bytes = (self.entTotal + self.relTotal) * self.hidden_size * 4
-        sparse = getattr(self, "sparse_rows", None)
+        requested = getattr(self, "sparse_rows", None)   # None = automatic, True / False = the caller's wish
+        sparse = requested
         if sparse is None:
             sparse = table_bytes > int(getattr(self, "sparse_threshold_bytes", 8 << 30))
         self.sparse_rows = bool(sparse) and self.use_counts and not self._adam
-        if sparse and not self.sparse_rows and getattr(self, "sparse_rows", None):
-            raise KgeError("sparse_rows needs TransE (sign-count path) with SGD")
+        if requested and not self.sparse_rows:
+            raise KgeError("sparse_rows needs TransE (sign-count path: 1..63 negatives) with SGD")
         self._grads = [] if self.sparse_rows else [torch.zeros_like(t) for t in self._tables]
         if self._adam:
             self._adam_m = [torch.zeros_like(t) for t in self._tables]

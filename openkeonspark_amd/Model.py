@@ -11,12 +11,13 @@ import numpy as np
 from . import _lib
 
 
-def xavier_normal(rng, shape):
+def xavier_normal(rng, shape, fan_in=None):
     """tf.contrib.layers.xavier_initializer(uniform=False) as the reference's get_variable calls use
     it (TransE.py:21-22): truncated normal, stddev sqrt(1.3 * 2 / (fan_in + fan_out)) with
-    fan_in = rows, fan_out = cols, values beyond two stddev re-drawn."""
+    fan_in = rows, fan_out = cols, values beyond two stddev re-drawn.  `fan_in` overrides the row count
+    of `shape` when only a slice of a larger variable is drawn (new-entity rows, main_spark.py:78)."""
     rows, cols = shape
-    std = np.sqrt(2.6 / (rows + cols))
+    std = np.sqrt(2.6 / ((rows if fan_in is None else fan_in) + cols))
     a = rng.standard_normal(shape)
     bad = np.abs(a) > 2.0
     while bad.any():

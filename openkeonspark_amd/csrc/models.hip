@@ -658,7 +658,8 @@ __global__ __launch_bounds__(256) void transe_emit_kernel(FbArgs a) {
 //   * e = f*x + B with B = (r^-t^), (h^+r^) or (h^-t^) precomputed per group and f = +-1/|x|:
 //     one fma per element;
 //   * sign(e) = med3(bits(e), -1, 1) on the integer pattern of the float (one instruction/element;
-//     -0.0 would read as -1, which can only arise from exact cancellation of negative zeros);
+//     -0.0 would read as -1, so the per-group constants are cleared of negative zeros, after which
+//     e = fma(f, x, B) can never be -0.0: tests/test_gpu_models.py::test_negative_zero_has_sign_zero);
 //   * the integer gradient vectors are packed int16 pairs (v_pk_add_i16), bytes only when stored;
 //   * one global_load_dwordx4 per row chunk.  Record dword w = lane + L*q holds elements 4w..4w+3
 //     ("natural" layout, flagged to the reducers).
@@ -746,10 +747,13 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
                 const float4 H = make_float4(hn[q].x * ih, hn[q].y * ih, hn[q].z * ih, hn[q].w * ih);
                 const float4 T = make_float4(tn[q].x * it, tn[q].y * it, tn[q].z * it, tn[q].w * it);
                 const float4 R = make_float4(rn[q].x * ir, rn[q].y * ir, rn[q].z * ir, rn[q].w * ir);
-                B0[q] = make_float4(R.x - T.x, R.y - T.y, R.z - T.z, R.w - T.w);
-                B1[q] = make_float4(H.x + R.x, H.y + R.y, H.z + R.z, H.w + R.w);
-                B2[q] = make_float4(H.x - T.x, H.y - T.y, H.z - T.z, H.w - T.w);
-                const float e0 = H.x + R.x - T.x, e1 = H.y + R.y - T.y, e2 = H.z + R.z - T.z, e3 = H.w + R.w - T.w;
+                // "+ 0.0f" turns a -0.0 into +0.0 (sign_of_bits reads the sign BIT; tf.sign(-0.0) is 0).  With B free of
+                // negative zeros, e = fma(f, x, B) cannot be -0.0 either: an exact cancellation rounds to +0.0, and
+                // (-0.0) + (+0.0) = +0.0.  Once per group, not per negative.
+                B0[q] = make_float4(R.x - T.x + 0.0f, R.y - T.y + 0.0f, R.z - T.z + 0.0f, R.w - T.w + 0.0f);
+                B1[q] = make_float4(H.x + R.x + 0.0f, H.y + R.y + 0.0f, H.z + R.z + 0.0f, H.w + R.w + 0.0f);
+                B2[q] = make_float4(H.x - T.x + 0.0f, H.y - T.y + 0.0f, H.z - T.z + 0.0f, H.w - T.w + 0.0f);
+                const float e0 = H.x + R.x - T.x + 0.0f, e1 = H.y + R.y - T.y + 0.0f, e2 = H.z + R.z - T.z + 0.0f, e3 = H.w + R.w - T.w + 0.0f;
                 acc += fabsf(e0) + fabsf(e1) + fabsf(e2) + fabsf(e3);
                 sp_lo[q] = pack16(sign_of_bits(e0), sign_of_bits(e1));
                 sp_hi[q] = pack16(sign_of_bits(e2), sign_of_bits(e3));

@@ -148,12 +148,15 @@ def save_checkpoint(con, output_path, max_to_keep=10):
 
 def grow_table(table, rows, rng, zeros=False):
     """Append rows for new entities (main_spark.py:74-98): xavier-initialised for a parameter table,
-    zeros for an Adam slot."""
+    zeros for an Adam slot.  The reference draws the WHOLE [final rows, dim] variable with the xavier
+    initializer (main_spark.py:78) and keeps its tail, so the new rows' stddev is sqrt(2.6/(rows+dim))
+    with rows = the final row count, not the number of appended rows."""
     table = np.asarray(table, dtype=np.float32)
     extra = rows - table.shape[0]
     if extra <= 0:
         return table
-    new = np.zeros((extra, table.shape[1]), np.float32) if zeros else xavier_normal(rng, (extra, table.shape[1]))
+    new = (np.zeros((extra, table.shape[1]), np.float32) if zeros
+           else xavier_normal(rng, (extra, table.shape[1]), fan_in=rows))
     return np.concatenate([table, new], axis=0)
 
 

@@ -74,3 +74,65 @@ def make_dataset(path, spec=None, **overrides):
         write_openke_dir(path, spec["entities"], spec["relations"], h, t, r)
         open(marker, "w").write("ok\n")
     return path
+
+
+# ---------------------------------------------------------------------------------------------------
+# Graphs with LEARNABLE structure, for metric-level checks (MR / Hits@10 of a trained model): the Zipf
+# graphs above have independent heads, tails and relations, so link prediction on them can only learn
+# entity popularity.  Here every entity has one of `types` latent types, relation r maps head type a to
+# tail type (a * mul_r + add_r) mod types, and a triple's tail is drawn (Zipf inside the type) from the
+# entities of the mapped type: a translational model that places types at distinct centroids ranks the
+# right tail among ~entities/types candidates instead of ~entities/2.
+# ---------------------------------------------------------------------------------------------------
+FB15K237_TYPED = dict(entities=14541, relations=237, train=272115, valid=17535, test=20466, types=64, seed=2370)
+SMALL_TYPED = dict(entities=1200, relations=12, train=20000, valid=300, test=400, types=12, seed=120)
+
+
+def generate_typed_triples(entities, relations, count, types, seed, ent_exponent=0.8, rel_exponent=1.0):
+    rng = np.random.default_rng(seed)
+    ent_type = rng.integers(0, types, entities)
+    by_type = [np.nonzero(ent_type == c)[0] for c in range(types)]
+    add = rng.integers(0, types, relations)
+    h = _zipf_draw(rng, entities, ent_exponent, count)
+    r = _zipf_draw(rng, relations, rel_exponent, count)
+    t_type = (ent_type[h] + add[r]) % types
+    t = np.empty(count, np.int64)
+    for c in range(types):
+        m = np.nonzero(t_type == c)[0]
+        if len(m):
+            members = by_type[c] if len(by_type[c]) else np.arange(entities)
+            t[m] = members[_zipf_draw(rng, len(members), ent_exponent, len(m))]
+    return h, t, r, ent_type
+
+
+def make_typed_dataset(path, spec=None, **overrides):
+    """train2id / valid2id / test2id (disjoint draws of the same generator; valid and test triples that
+    also occur in train are kept, as in real splits they would not be -- the filtered ranks handle
+    them) plus type_constrain.txt in the format Reader.h:317-330 reads.  Returns the path."""
+    spec = dict(spec or FB15K237_TYPED)
+    spec.update(overrides)
+    if not path.endswith("/"):
+        path += "/"
+    marker = os.path.join(path, ".complete")
+    if os.path.exists(marker):
+        return path
+    E, R = spec["entities"], spec["relations"]
+    total = spec["train"] + spec["valid"] + spec["test"]
+    h, t, r, _ = generate_typed_triples(E, R, total, spec["types"], spec["seed"])
+    n_tr, n_va = spec["train"], spec["valid"]
+    write_openke_dir(path, E, R, h[:n_tr], t[:n_tr], r[:n_tr])
+    for name, sl in (("valid2id.txt", slice(n_tr, n_tr + n_va)), ("test2id.txt", slice(n_tr + n_va, total))):
+        with open(os.path.join(path, name), "w") as f:
+            f.write("%d\n" % (sl.stop - sl.start))
+            np.savetxt(f, np.stack([h[sl], t[sl], r[sl]], axis=1), fmt="%d")
+    with open(os.path.join(path, "type_constrain.txt"), "w") as f:   # per relation: heads seen, then tails seen
+        f.write("%d\n" % R)
+        order = np.argsort(r, kind="stable")
+        bounds = np.searchsorted(r[order], np.arange(R + 1))
+        for rel in range(R):
+            idx = order[bounds[rel]:bounds[rel + 1]]
+            heads = np.unique(h[idx]); tails = np.unique(t[idx])
+            f.write("%d\t%d%s\n" % (rel, len(heads), "".join("\t%d" % x for x in heads)))
+            f.write("%d\t%d%s\n" % (rel, len(tails), "".join("\t%d" % x for x in tails)))
+    open(marker, "w").write("ok\n")
+    return path

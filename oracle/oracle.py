@@ -288,6 +288,20 @@ class Model:
             lib().orc_sgd_apply_dense(_p(self.params[k]), _p(g[k]), g[k].size, lr)
         return loss
 
+    def apply_sgd(self, g, lr):
+        """GradientDescentOptimizer on an already summed gradient (as returned by grad())."""
+        self.step += 1
+        for k in self.names:
+            lib().orc_sgd_apply_dense(_p(self.params[k]), _p(g[k]), g[k].size, lr)
+
+    def apply_adam(self, g, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        """AdamOptimizer (TF1 sparse = dense sweep) on an already summed gradient."""
+        self.step += 1
+        lr_t = adam_lr_t(lr, beta1, beta2, self.step)
+        for k in self.names:
+            lib().orc_adam_apply_dense(_p(self.params[k]), _p(self.adam_m[k]), _p(self.adam_v[k]), _p(g[k]),
+                                       g[k].size, lr_t, beta1, beta2, eps)
+
     def adam_step(self, bh, bt, br, B, N, lr, beta1=0.9, beta2=0.999, eps=1e-8, nthreads=1):
         """One AdamOptimizer step on IndexedSlices gradients (distribute_training.py:95-96,101)."""
         self.step += 1

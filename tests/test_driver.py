@@ -29,7 +29,10 @@ def test_grow_table_appends_xavier_or_zero_rows():
     t = np.ones((5, 8), np.float32)
     g = dt.grow_table(t, 9, rng)
     assert g.shape == (9, 8) and np.array_equal(g[:5], t) and np.abs(g[5:]).max() > 0
-    assert np.abs(g[5:]).max() <= 2 * np.sqrt(2.6 / (4 + 8)) + 1e-6      # truncated at two stddev
+    # main_spark.py:78 draws the whole [final rows, dim] variable: stddev sqrt(2.6 / (9 + 8)), truncated at two stddev
+    assert np.abs(g[5:]).max() <= 2 * np.sqrt(2.6 / (9 + 8)) + 1e-6
+    big = dt.grow_table(np.ones((14541, 64), np.float32), 14551, np.random.default_rng(1))
+    assert abs(big[14541:].std() / (0.88 * np.sqrt(2.6 / (14551 + 64))) - 1) < 0.15   # 0.88 = std of a 2-sigma truncated normal
     z = dt.grow_table(t, 9, rng, zeros=True)
     assert not z[5:].any()
     assert dt.grow_table(t, 5, rng) is not None and dt.grow_table(t, 3, rng).shape == (5, 8)

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, parity_report
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -69,6 +69,8 @@ def test_device_link_prediction_matches_oracle(model):
             if got.tolist() != want.tolist():
                 mismatched += 1
                 assert np.abs(got[:4] - want[:4]).max() <= 1, (k, got, want)
+    parity_report("device_link_prediction_vs_oracle[%s]" % model,
+                  eight_vectors_differing_by_one_count=mismatched, of=2 * n, bound=2)
     assert mismatched <= 2
     assert 0.0 <= metrics["r_filter_tot"] <= 1.0 and metrics["r_rank"] >= 1.0 and metrics["l_filter_rank"] >= 1.0
     assert metrics["r_filter_rank"] <= metrics["r_rank"]

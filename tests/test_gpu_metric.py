@@ -1,0 +1,93 @@
+"""Metric-level parity: MR / Hits@10 (BASELINE.json's metric) of a model TRAINED by the engine against the same model
+trained by the CPU oracle from the same initial parameters and the same sampler seeds.
+
+The reference computes the metric with `testHead / testTail` over the test set (distribute_training.py:465-527,
+Test.h:31-249) and reduces it in main_spark.py:430-448.  Here:
+  * both trainers draw bit-identical batches (checked elsewhere) and start from identical tables; their fp32
+    trajectories drift apart by rounding (different summation orders, hinges near their switch point), so the
+    PARAMETERS after thousands of steps are not comparable element-wise -- the METRICS must be;
+  * the engine-trained and the oracle-trained tables are both ranked by the device ranker (`kge_link_prediction`, itself
+    bit-exact against the compiled reference's testHead/testTail fixtures, tests/test_gpu_lp.py), over the WHOLE test set;
+  * on a sample of test triples the oracle's own ranker (oracle predict + Test.h restatement) is run on the
+    oracle-trained tables and must give the device ranker's 8-vectors;
+  * training must improve the metric against the untrained model.
+Graphs: typed synthetic KGs (openkeonspark_amd/synthetic.py: learnable structure; the reference ships no data)."""
+import numpy as np
+import pytest
+
+from conftest import parity_report
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def train_both(path, dim, nbatches, n, alpha, epochs, threads=8):
+    import openkeonspark_amd as pkg
+    con = pkg.Config()
+    con.prefetch_sampling = False
+    con.set_in_path(path); con.set_work_threads(8); con.set_bern(0); con.set_dimension(dim); con.set_nbatches(nbatches)
+    con.set_ent_neg_rate(n); con.set_alpha(alpha); con.set_margin(1.0); con.set_opt_method("SGD")
+    con.set_test_link_prediction(True)
+    con.init()
+    con.set_model_and_session(pkg.TransE)
+    init = con.get_parameters()
+    kg = oracle.KG(path, work_threads=8, bern=0)
+    kg.set_stream_states(con.get_stream_states())
+    orc = oracle.Model("transe", con.entTotal, con.relTotal, dim, dim, margin=1.0, params=init)
+    B = con.batch_size
+    _, untrained = con.link_prediction(test_head=True)
+    steps = epochs * con.nbatches
+    loss_g = loss_o = None
+    for _ in range(steps):
+        loss_g = con.train_step(sync=False)
+        bh, bt, br, _ = kg.sampling(B, n, 0)
+        loss_o = orc.sgd_step(bh, bt, br, B, n, alpha, nthreads=threads)
+    loss_g = float(loss_g.item())
+    assert con.get_stream_states().tolist() == kg.stream_states().tolist()      # the same batches were drawn throughout
+    out_g, met_g = con.link_prediction(test_head=True)
+    con.set_parameters(orc.params)
+    out_o, met_o = con.link_prediction(test_head=True)
+    return con, orc, untrained, (out_g, met_g, loss_g), (out_o, met_o, loss_o), steps
+
+
+KEYS = ("r_filter_rank", "l_filter_rank", "r_filter_tot", "l_filter_tot", "r_rank", "l_rank", "r_tot", "l_tot")
+
+
+@pytest.mark.parametrize("graph", ["small_typed", "fb15k237_typed"])
+def test_trained_model_reaches_the_oracle_trained_metrics(graph):
+    from openkeonspark_amd.synthetic import make_typed_dataset, FB15K237_TYPED, SMALL_TYPED
+    if graph == "small_typed":
+        path = make_typed_dataset("/tmp/okes_typed_small", SMALL_TYPED)
+        dim, nbatches, n, alpha, epochs, sample = 32, 10, 4, 3.0, 40, 200
+    else:   # configs[0]'s shape: FB15k-237 cardinalities, dim 100, the auto batch 2 721 (nbatches 100)
+        path = make_typed_dataset("/tmp/okes_typed_fb", FB15K237_TYPED)
+        dim, nbatches, n, alpha, epochs, sample = 100, 100, 4, 10.0, 30, 150
+    con, orc, untrained, (out_g, met_g, loss_g), (out_o, met_o, loss_o), steps = train_both(path, dim, nbatches, n, alpha, epochs)
+    # (1) the oracle's own ranker on the oracle-trained tables == the device ranker's 8-vectors (sample of the test set)
+    ev = oracle.Eval(path)
+    E = con.entTotal
+    ar = np.arange(E)
+    flips = 0
+    for i in range(min(sample, ev.testTotal)):
+        h, t, r = ev.test_triple(i)
+        want_t = ev.rank(i, orc.predict(np.full(E, h), ar, np.full(E, r)), head=False)
+        want_h = ev.rank(i, orc.predict(ar, np.full(E, t), np.full(E, r)), head=True)
+        for got, want in ((out_o[i, 0], want_t), (out_o[i, 1], want_h)):
+            if got[:2].tolist() != want[:2].tolist():       # raw and filtered counts (type files: constrained counts too)
+                flips += 1
+                assert np.abs(got[:4] - want[:4]).max() <= 1, (i, got, want)   # a candidate within an ulp of the target
+    # (2) metric-level agreement of the two trainers, whole test set, both sides
+    report = dict(graph=graph, steps=steps, test_triples=int(ev.testTotal), final_loss_engine=loss_g, final_loss_oracle=loss_o,
+                  ranker_vectors_differing_by_one=flips, ranker_vectors_checked=2 * min(sample, ev.testTotal))
+    for k in KEYS:
+        report[k] = dict(untrained=untrained[k], engine=met_g[k], oracle=met_o[k])
+    parity_report("metric_parity[%s]" % graph, **report)
+    assert flips <= 2
+    for side in ("r", "l"):
+        mr_g, mr_o, mr_0 = met_g[side + "_filter_rank"], met_o[side + "_filter_rank"], untrained[side + "_filter_rank"]
+        h10_g, h10_o, h10_0 = met_g[side + "_filter_tot"], met_o[side + "_filter_tot"], untrained[side + "_filter_tot"]
+        assert abs(mr_g - mr_o) <= 0.03 * mr_o, (side, mr_g, mr_o)                 # filtered MR within 3 %
+        assert abs(h10_g - h10_o) <= 0.02, (side, h10_g, h10_o)                    # filtered Hits@10 within 0.02 absolute
+        assert mr_g < 0.75 * mr_0 and mr_o < 0.75 * mr_0, (side, mr_g, mr_o, mr_0)  # training helps: MR falls by > 25 %
+        assert h10_g > h10_0 and h10_o > h10_0
+    assert abs(loss_g - loss_o) <= 0.1 * max(loss_o, 1e-3) + 0.01

@@ -6,11 +6,16 @@ tests/test_oracle_models.py."""
 import numpy as np
 import pytest
 
+from conftest import parity_report
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5
+# carve-outs, each reported through parity_report with the count actually seen (bounds = the counts observed on MI355X
+# when they were last revised; a regression inside a bound still shows in gpurun_out/parity_counts.jsonl)
+SIGN_FLIP_ROWS_BOUND = 4     # rows of a table whose gradient carries one sign flip of an element within rounding of zero
+EXACT_COUNT_ROWS_BOUND = 2   # rows of the integer count image touched by a hinge within rounding of its switch point
 
 
 def relerr(a, b):
@@ -175,6 +180,7 @@ def test_training_steps_match_oracle(model, opt, grad_path):
     alpha = 0.05 if opt == "SGD" else 0.01
     orc = oracle.Model(model, E, R, D, D, margin=1.0, params=params)
     con = make_engine(model, E, R, D, n, 0, margin=1.0, opt=opt, alpha=alpha, params=params)
+    adam_bad, adam_worst = {}, 0.0
     for step in range(5):
         bh, bt, br = rand_batch(rng, E, R, B, n, 0)
         lo = orc.sgd_step(bh, bt, br, B, n, alpha) if opt == "SGD" else orc.adam_step(bh, bt, br, B, n, alpha)
@@ -191,7 +197,12 @@ def test_training_steps_match_oracle(model, opt, grad_path):
                 assert np.abs(du_g - du_o).max() <= 1e-4 * np.abs(du_o).max(), (step, k)
             else:
                 bad = np.abs(du_g - du_o) > 1e-3 * np.abs(du_o).max()
+                adam_bad[k] = max(adam_bad.get(k, 0), int(bad.sum()))
+                adam_worst = max(adam_worst, float(np.abs(du_g - du_o).max() / alpha))
                 assert bad.sum() <= max(3, 2e-3 * bad.size) and np.abs(du_g - du_o).max() <= 4 * alpha, (step, k, bad.sum())
+    if opt == "Adam":
+        parity_report("training_steps_match_oracle[%s-Adam-%s]" % (model, grad_path), elements_outside_1e3_of_update=adam_bad,
+                      worst_in_steps_of_alpha=adam_worst, bound_elements="max(3, 0.2%)", bound_steps=4)
     assert con.global_step == 5
     for g in con.get_gradients().values():
         assert not g.any()  # accumulators are re-zeroed by the update kernels
@@ -228,6 +239,7 @@ def test_transe_sign_count_gradient_matches_oracle(D, n, nr, foreign, reducer):
     assert abs(loss_g - loss_o) <= RTOL * abs(loss_o)
     got = con.get_parameters()
     unit = 1.0 / (B * (n + nr))
+    flips = {}
     for k in g_o:
         g_g = params[k].astype(np.float64) - got[k].astype(np.float64)
         # p - 1.0*g is rounded to fp32 at the parameter's magnitude: allow that quantum on top of 1e-5
@@ -242,8 +254,11 @@ def test_transe_sign_count_gradient_matches_oracle(D, n, nr, foreign, reducer):
         # row must agree to 1e-5.
         min_norm = np.sqrt((params[k].astype(np.float64) ** 2).sum(1)).min()
         bad_rows = np.nonzero(bad.any(1))[0]
-        assert len(bad_rows) <= 4, (k, len(bad_rows))
+        flips[k] = len(bad_rows)
+        assert len(bad_rows) <= SIGN_FLIP_ROWS_BOUND, (k, len(bad_rows))
         assert diff.max() <= 2.05 * unit / min_norm + RTOL * np.abs(g_o[k]).max() + quantum, (k, diff.max())
+    parity_report("transe_sign_count_gradient[D=%d n=%d nr=%d foreign=%.1f %s]" % (D, n, nr, foreign, reducer),
+                  rows_with_a_sign_flip=flips, bound_rows=SIGN_FLIP_ROWS_BOUND)
     assert not con._counts.any().item()
     for g in con.get_gradients().values():
         assert not g.any()
@@ -286,7 +301,9 @@ def test_transe_sign_counts_are_the_exact_integer_sums(D, n, reducer):
     want = numpy_sign_counts(params, bh, bt, br, B, n, 1.0)
     bad_rows = np.nonzero((got != want).any(1))[0]
     # a hinge within rounding of zero may legitimately flip: allow a couple of rows, not a pattern
-    assert len(bad_rows) <= 2, (len(bad_rows), bad_rows[:10], np.abs(got - want).max())
+    parity_report("transe_sign_counts_exact[D=%d n=%d %s]" % (D, n, reducer), rows_differing=len(bad_rows),
+                  largest_count_difference=int(np.abs(got - want).max()), bound_rows=EXACT_COUNT_ROWS_BOUND)
+    assert len(bad_rows) <= EXACT_COUNT_ROWS_BOUND, (len(bad_rows), bad_rows[:10], np.abs(got - want).max())
     con._counts.zero_()
 
 
@@ -316,6 +333,9 @@ def test_transe_sign_count_training_tracks_oracle(D, n, opt):
         else:
             # a handful of near-cancelling elements may differ by a fraction of one Adam step
             bad = np.abs(du_g - du_o) > 1e-3 * np.abs(du_o).max()
+            parity_report("transe_sign_count_training[D=%d n=%d Adam] %s" % (D, n, k), elements_outside_1e3_of_update=int(bad.sum()),
+                          of_elements=int(bad.size), worst_in_steps_of_alpha=float(np.abs(du_g - du_o).max() / alpha),
+                          bound_elements="max(3, 0.2%)", bound_steps=4)
             assert bad.sum() <= max(3, 2e-3 * bad.size) and np.abs(du_g - du_o).max() <= 4 * alpha, (k, bad.sum())
 
 
@@ -540,3 +560,34 @@ def test_out_of_range_ids_are_rejected_on_the_host():
             con.test_step(*bad)
         with pytest.raises(KgeError):
             con.train_step(bad[0], bad[1], bad[2], None)
+
+
+@pytest.mark.parametrize("D", [16, 200])
+def test_negative_zero_has_sign_zero(D, reducer):
+    """tf.sign(-0.0) is 0 (TransE.py:15 abs -> its gradient sign(e)).  The vectorised emit kernel reads the sign from the
+    bit pattern of e, where -0.0 would read as -1: rows are built so that e = h^ + r^ - t^ is EXACTLY -0.0 in whole columns
+    ((-0) + (-0) - (+0) for the positive, fma(f, -0, -0) for corrupted heads / tails / relation vectors) and exactly +0.0 in
+    others.  The integer counts must equal the definition's (numpy: sign(+-0) = 0) with no tolerance in those columns."""
+    import torch
+    rng = np.random.default_rng(D)
+    E, R, B, n = 40, 4, 256, 6
+    params = oracle.init_params(oracle.TRANSE, E, R, D, D, seed=12)
+    ent, rel = params["ent_embeddings"], params["rel_embeddings"]
+    ent[0::2, 0] = -0.0; ent[1::2, 0] = 0.0          # column 0: even entities -0, odd entities +0
+    rel[:, 0] = -0.0
+    ent[:, 1] = 0.0; rel[:, 1] = 0.0                 # column 1: all +0 -> e = +0
+    ent[:, 2] = -0.0; rel[:, 2] = 0.0                # column 2: (-0) + (+0) - (-0) = +0
+    ent[:, 3] = -0.0; rel[:, 3] = -0.0               # column 3: (-0) + (-0) - (-0) = +0 (IEEE: -0 + +0)
+    bh, bt, br = rand_batch(rng, E, R, B, n, 2, distinct=True)
+    con = make_engine("transe", E, R, D, n, 2, margin=1.0, params=params)
+    assert np.signbit(con.get_parameters()["ent_embeddings"][0, 0])          # the negative zeros reached the device
+    dev = torch.from_numpy(np.stack([bh, bt, br]).astype(np.int32)).cuda()
+    con.forward_counts(dev, B, B, B * (n + 2))
+    got = con._counts.cpu().numpy().astype(np.int64)
+    want = numpy_sign_counts(params, bh, bt, br, B, n + 2, 1.0)
+    assert int(np.abs(want[:, 4:]).sum()) > 0
+    assert not got[:, :4].any(), np.nonzero(got[:, :4])
+    bad_rows = np.nonzero((got != want).any(1))[0]
+    parity_report("negative_zero_sign[D=%d %s]" % (D, reducer), rows_differing=len(bad_rows), bound_rows=EXACT_COUNT_ROWS_BOUND)
+    assert len(bad_rows) <= EXACT_COUNT_ROWS_BOUND
+    con._counts.zero_()
