@@ -8,9 +8,9 @@ configs[4]  50 M-entity TransE dim 512       (TransE.py:11-51)   sparse-row step
                                                                    oracle, and size-independent properties at full size
 Batch rule: Config.py:189-210.  Each test first checks the device sampler bit for bit against the oracle's
 batch (Base.cpp:74-172), then loss, summed gradients and the SGD parameters (distribute_training.py:98-101) to the
-1e-5 relative tolerance of BASELINE.json's north_star.  Rows that fall outside it are COUNTED, reported and bounded
-at the count observed when the test was written: a hinge within fp32 rounding of zero switches whole gradient rows
-(max(x, 0) at x ~ 0), which is a property of the loss, not of either implementation."""
+1e-5 relative tolerance of BASELINE.json's north_star.  Rows that fall outside it are COUNTED, reported, bounded and
+each one EXPLAINED: it must belong to a group in which an element of e = h^ + r^ - t^ is within fp32 rounding of zero
+(d|e|/de jumps there), which is a property of the loss, not of either implementation."""
 import numpy as np
 import pytest
 
@@ -20,14 +20,6 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5
-
-
-def rows_outside(got, want, rtol=RTOL):
-    """(number of rows with an element off by more than rtol * max|want|, largest relative error)."""
-    scale = np.abs(want).max() + 1e-30
-    diff = np.abs(got.astype(np.float64) - want)
-    bad = (diff > rtol * scale).reshape(want.shape[0], -1).any(1)
-    return int(bad.sum()), float(diff.max() / scale)
 
 
 def near_ties(orc, bh, bt, br, B, N, eps=2e-6):
@@ -45,11 +37,18 @@ def check_sampled_batch(con, kg, B, n):
     return dev, bh, bt, br
 
 
-def run_steps(con, kg, orc, B, n, alpha, steps, name, max_bad_rows):
+def run_steps(con, kg, orc, B, n, alpha, steps, name, model, dims):
+    """`steps` SGD steps on device-sampled batches.  Every step the oracle starts from the ENGINE's current tables, so
+    each comparison is of one forward/backward/update on identical inputs.  Rows outside 1e-5 must be explained: they
+    have to be rows of a group in which some element of e = h^ + r^ - t^ lies within fp32 rounding of zero (fp64
+    evaluation, tests/torch_ref.py::near_kink_rows) -- the one place where two correct fp32 evaluations of this loss
+    legitimately differ by more than rounding."""
     import torch
-    p0 = {k: v.copy() for k, v in orc.params.items()}
-    worst = dict(loss=0.0, grad=0.0, bad_rows=0, ties=0, update=0.0)
+    from torch_ref import near_kink_rows
+    worst = dict(loss=0.0, grad=0.0, grad_rows=0, update_rows=0, ties=0, kink_elems=0)
     for step in range(steps):
+        start = con.get_parameters()
+        orc.params = {k: v.copy() for k, v in start.items()}
         dev, bh, bt, br = check_sampled_batch(con, kg, B, n)
         worst["ties"] += near_ties(orc, bh, bt, br, B, n)
         loss_o, g_o = orc.grad(bh, bt, br, B, n)
@@ -58,27 +57,36 @@ def run_steps(con, kg, orc, B, n, alpha, steps, name, max_bad_rows):
         loss_g = float(con._loss.item())
         worst["loss"] = max(worst["loss"], abs(loss_g - loss_o) / abs(loss_o))
         g_g = con.get_gradients()
-        for k in g_o:
-            nbad, err = rows_outside(g_g[k], g_o[k])
-            worst["bad_rows"] += nbad
-            if nbad == 0:
-                worst["grad"] = max(worst["grad"], err)
         con.apply_gradients()
         orc.apply_sgd(g_o, alpha)
-    got = con.get_parameters()
-    for k in orc.params:
-        du_o = orc.params[k].astype(np.float64) - p0[k]
-        du_g = got[k].astype(np.float64) - p0[k]
-        quantum = np.abs(p0[k]).max() * 2.0 ** -23 * steps          # p - lr*g is rounded at the parameter's magnitude
-        nbad = int((np.abs(du_g - du_o) > RTOL * np.abs(du_o).max() + quantum).reshape(du_o.shape[0], -1).any(1).sum())
-        worst["update"] = max(worst["update"], nbad)
+        got = con.get_parameters()
+        kink = None
+        for k in g_o:
+            scale = np.abs(g_o[k]).max() + 1e-30
+            diff = np.abs(g_g[k].astype(np.float64) - g_o[k])
+            bad = np.nonzero((diff > RTOL * scale).reshape(diff.shape[0], -1).any(1))[0]
+            du_o = orc.params[k].astype(np.float64) - start[k]
+            du_g = got[k].astype(np.float64) - start[k]
+            quantum = np.abs(start[k]).max() * 2.0 ** -23           # p - lr*g is rounded at the parameter's magnitude
+            bad_u = np.nonzero((np.abs(du_g - du_o) > RTOL * np.abs(du_o).max() + quantum).reshape(diff.shape[0], -1).any(1))[0]
+            worst["grad_rows"] += len(bad); worst["update_rows"] += len(bad_u)
+            clean = np.ones(diff.shape[0], bool); clean[bad] = False
+            if clean.any():
+                worst["grad"] = max(worst["grad"], float(diff[clean].max() / scale))
+            if len(bad) or len(bad_u):
+                if kink is None:
+                    kink, n_el = near_kink_rows(model, start, bh, bt, br, B, n, dims[0], dims[1], tol=1e-6)
+                    worst["kink_elems"] += n_el
+                unexplained = (set(bad.tolist()) | set(bad_u.tolist())) - kink[k]
+                assert not unexplained, (name, step, k, sorted(unexplained)[:10], "rows outside 1e-5 with no |e| < 1e-6 nearby")
     assert con.get_stream_states().tolist() == kg.stream_states().tolist()
-    parity_report(name, batch=B, steps=steps, loss_relerr=worst["loss"], grad_relerr_clean_tables=worst["grad"],
-                  grad_rows_outside_1e5=worst["bad_rows"], update_rows_outside_1e5=worst["update"],
-                  near_tie_hinges=worst["ties"], bound_rows=max_bad_rows)
+    parity_report(name, batch=B, steps=steps, loss_relerr=worst["loss"], grad_relerr_other_rows=worst["grad"],
+                  grad_rows_outside_1e5=worst["grad_rows"], update_rows_outside_1e5=worst["update_rows"],
+                  elements_of_e_within_1e6_of_zero=worst["kink_elems"], near_tie_hinges=worst["ties"])
     assert worst["loss"] <= RTOL, worst
     assert worst["grad"] <= RTOL, worst
-    assert worst["bad_rows"] <= max_bad_rows and worst["update"] <= max_bad_rows, worst
+    # every outside row was explained above; bound their number too (a flipped element reaches the <= 6 rows of its group)
+    assert worst["grad_rows"] <= 6 * max(worst["kink_elems"], 0) and worst["grad_rows"] <= 24, worst
 
 
 def engine(path, model, dim, nbatches, n, alpha, bern=0):
@@ -106,7 +114,7 @@ def test_config3_wn18rr_transh(wn_dir, nbatches, B, path):
     kg = oracle.KG(wn_dir, work_threads=8, bern=0)
     kg.set_stream_states(con.get_stream_states())
     orc = oracle.Model("transh", con.entTotal, con.relTotal, 200, 200, margin=1.0, params=con.get_parameters())
-    run_steps(con, kg, orc, B, n, alpha, steps=3, name="config3 WN18RR TransH D=200 B=%d (%s)" % (B, path), max_bad_rows=0)
+    run_steps(con, kg, orc, B, n, alpha, steps=3, name="config3 WN18RR TransH D=200 B=%d (%s)" % (B, path), model="transh", dims=(200, 200))
     _lib.raise_if_error(con.lib)
 
 
@@ -122,7 +130,7 @@ def test_config4_fb15k237_transr(fb_dir, nbatches, B):
     kg.set_stream_states(con.get_stream_states())
     orc = oracle.Model("transr", con.entTotal, con.relTotal, 200, 200, margin=1.0, params=con.get_parameters())
     # B = 34 014: relations with >= 256 rows take the all-output-tiles wgrad, the skewed rest the 32-row tiles (transr.hip)
-    run_steps(con, kg, orc, B, n, alpha, steps=2, name="config4 FB15k-237 TransR 200x200 B=%d" % B, max_bad_rows=0)
+    run_steps(con, kg, orc, B, n, alpha, steps=2, name="config4 FB15k-237 TransR 200x200 B=%d" % B, model="transr", dims=(200, 200))
 
 
 def test_config1_fb15k237_transe_auto_batch(fb_dir):
@@ -133,7 +141,7 @@ def test_config1_fb15k237_transe_auto_batch(fb_dir):
     kg = oracle.KG(fb_dir, work_threads=8, bern=0)
     kg.set_stream_states(con.get_stream_states())
     orc = oracle.Model("transe", con.entTotal, con.relTotal, 100, 100, margin=1.0, params=con.get_parameters())
-    run_steps(con, kg, orc, 2721, n, alpha, steps=3, name="config1 FB15k-237 TransE D=100 B=2721", max_bad_rows=0)
+    run_steps(con, kg, orc, 2721, n, alpha, steps=3, name="config1 FB15k-237 TransE D=100 B=2721", model="transe", dims=(100, 100))
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -54,3 +54,48 @@ def loss_and_grads(model, params, bh, bt, br, B, N, margin, De, Dr, negative_rel
     loss = loss_fn(model, P, bh, bt, br, B, N, margin, De, Dr, negative_rel)
     loss.backward()
     return float(loss.detach()), {k: (v.grad.numpy() if v.grad is not None else None) for k, v in P.items()}
+
+
+def near_kink_rows(model, params, bh, bt, br, B, N, De, Dr, tol=1e-6, negative_rel=0):
+    """Rows of every table whose gradient a sign flip of d|e|/de could change: the score is sum |e| with
+    e = h^ + r^ - t^ (TransE.py:15), whose derivative jumps at e = 0, so an element of e within fp32 rounding
+    of zero gets sign +1 from one evaluation order and -1 (or 0) from another.  Evaluated here in fp64 from the
+    given parameters.  Returns ({table: set(rows)}, number of elements with |e| < tol).  Only rows of triples
+    whose hinge could be active matter, but every near-zero element is reported (a superset)."""
+    import numpy as np
+    P = {k: torch.tensor(np.asarray(v), dtype=torch.float64) for k, v in params.items()}
+    bh, bt, br = [torch.as_tensor(np.asarray(x), dtype=torch.long) for x in (bh, bt, br)]
+    ent, rel = P["ent_embeddings"], P["rel_embeddings"]
+    n_tr = B * (1 + N)
+    pos_of = torch.arange(n_tr) % B                      # triple j belongs to positive j % B (Base.cpp:109-139)
+    if model == "transe":
+        e = l2n(ent[bh]) + l2n(rel[br]) - l2n(ent[bt])
+    elif model == "transh":
+        w = l2n(P["normal_vectors"][br])
+        tr = lambda x: x - (x * w).sum(-1, keepdim=True) * w
+        e = l2n(tr(ent[bh])) + l2n(rel[br]) - l2n(tr(ent[bt]))
+    elif model == "transd":
+        et, rt = P["ent_transfer"], P["rel_transfer"]
+        tr = lambda ids: ent[ids] + (ent[ids] * et[ids]).sum(-1, keepdim=True) * rt[br]
+        e = l2n(tr(bh)) + l2n(rel[br]) - l2n(tr(bt))
+    else:   # transr: the matrix is the POSITIVE's when negative_rel == 0 (TransR.py:57-60)
+        M = P["transfer_matrix"]
+        mr = br if negative_rel else br[pos_of]
+        e = torch.empty((n_tr, Dr), dtype=torch.float64)
+        for r in torch.unique(mr).tolist():
+            idx = torch.nonzero(mr == r).squeeze(1)
+            m = M[r].view(De, Dr)
+            e[idx] = l2n(ent[bh[idx]] @ m) + l2n(rel[br[idx]]) - l2n(ent[bt[idx]] @ m)
+    near = (e.abs() < tol).any(-1)
+    groups = torch.unique(pos_of[near])                  # a flip in any triple of a group reaches the group's shared rows
+    member = torch.isin(pos_of, groups)
+    rows = {k: set() for k in params}
+    hs, ts, rs = bh[member].tolist(), bt[member].tolist(), br[member].tolist()
+    rows["ent_embeddings"].update(hs); rows["ent_embeddings"].update(ts)
+    rows["rel_embeddings"].update(rs)
+    for k in ("normal_vectors", "rel_transfer", "transfer_matrix"):
+        if k in rows:
+            rows[k].update(rs)
+    if "ent_transfer" in rows:
+        rows["ent_transfer"].update(hs); rows["ent_transfer"].update(ts)
+    return rows, int((e.abs() < tol).sum())
