@@ -238,6 +238,12 @@ int kge_transe_apply_counts_tables(const kge_model_desc *m, float *const d_p[2],
                                    int32_t *d_counts, float *const d_resid[2], INT denom, int32_t adam, float lr, float beta1,
                                    float beta2, float eps, void *stream);
 
+/* the same on the row range [row_lo, row_hi) of the [(E+R), D] row space only; d_counts_chunk = the count image OF THAT RANGE
+ * (a data-parallel rank's reduce-scattered chunk): owner-computes update, replaces the replicated optimizer sweep */
+int kge_transe_apply_counts_range(const kge_model_desc *m, float *const d_p[2], float *const d_m[2], float *const d_v[2],
+                                  int32_t *d_counts_chunk, float *const d_resid[2], INT row_lo, INT row_hi, INT denom, int32_t adam,
+                                  float lr, float beta1, float beta2, float eps, void *stream);
+
 /* ---- TransE sign-count path, stage level: for tables too large for a dense count image and for the
  * multi-GPU exchange, where the int8 records (8x smaller than fp32 gradient rows) are the wire format ----
  *   kge_transe_record_dwords : dwords per record for this embedding width
@@ -268,6 +274,36 @@ int kge_transe_apply_rows_sgd(const kge_model_desc *m, float *d_ent, float *d_re
 int kge_transe_reduce_apply_records_sgd(const kge_model_desc *m, const uint32_t *d_rec, int32_t *d_dst, INT n_records, float *d_ent,
                                         float *d_rel, int32_t *d_rows, int32_t *d_row_counts, int32_t *d_n_rows, INT denom, float lr,
                                         void *stream);
+
+/* ---- Table-sharded sparse path (N GPUs, BASELINE config #5): rank g OWNS the entity rows [g*chunk, (g+1)*chunk); what the
+ * reference does with ps tasks holding the variables and workers pulling rows / pushing IndexedSlices over gRPC
+ * (distribute_training.py:193-196) becomes: request ids -> all-to-all -> owners gather rows -> all-to-all -> emit records
+ * against the fetched rows -> all-to-all (row id, record) -> owners reduce + apply their rows.  These are the device stages
+ * between the collectives (csrc/shard.hip); the collectives themselves are torch.distributed all_to_all_single (RCCL).
+ *   kge_shard_requests      : d_req[slot*n_pos + b] = entity touched by record slot (slot, b) of the emit kernel, -1 if none
+ *                             (slot 0/1 = the positive's head/tail, 2 = relation, 3+k = the new entity of negative k)
+ *   kge_shard_count         : d_counts[o] = how many of d_ids (ids < 0 skipped) rank o = id / chunk owns   (n_owners <= 64)
+ *   kge_shard_scatter       : d_sorted = the live ids grouped by owner (h_counts = HOST copy of d_counts), d_slot_of[i] = position of
+ *                             d_ids[i] in d_sorted or -1; d_cursor = n_owners ints of scratch
+ *   kge_shard_remap_batch   : the batch with entity ids replaced by positions in the fetched-row list (d_slot_of from the
+ *                             requests), so the unchanged emit kernel runs against the fetched rows as its "entity table"
+ *   kge_shard_gather_rows   : d_out[i,:] = d_table[d_ids[i] - row_lo, :]  (the owner's reply; dim % 4 == 0)
+ *   kge_shard_record_ids    : d_ids[m] = global entity id of record m when its destination is a fetched-row slot, else -1
+ *   kge_shard_pack_records  : d_out[d_slot_of[m], :] = d_rec[m, :] for the records that travel
+ *   kge_shard_relation_counts: relation records (destination >= cache_rows) summed into the dense int32 image [R, dim]
+ *                             (zero it first; all-reduced across ranks, the small relation table stays replicated) */
+int kge_shard_requests(const int32_t *d_h, const int32_t *d_t, const int32_t *d_r, INT n_pos, INT n_neg, INT stride, int32_t *d_req,
+                       void *stream);
+int kge_shard_count(const int32_t *d_ids, INT n, INT chunk, INT n_owners, int32_t *d_counts, void *stream);
+int kge_shard_scatter(const int32_t *d_ids, INT n, INT chunk, INT n_owners, const INT *h_counts, int32_t *d_cursor, int32_t *d_sorted,
+                      int32_t *d_slot_of, void *stream);
+int kge_shard_remap_batch(const int32_t *d_h, const int32_t *d_t, INT n_pos, INT n_neg, INT stride, const int32_t *d_slot_of, int32_t *d_h2,
+                          int32_t *d_t2, void *stream);
+int kge_shard_gather_rows(const float *d_table, const int32_t *d_ids, INT n, INT row_lo, INT rows, INT dim, float *d_out, void *stream);
+int kge_shard_record_ids(const int32_t *d_dst, INT n_records, INT cache_rows, const int32_t *d_cache_ids, int32_t *d_ids, void *stream);
+int kge_shard_pack_records(const uint32_t *d_rec, const int32_t *d_slot_of, INT n_records, INT dwords, uint32_t *d_out, void *stream);
+int kge_shard_relation_counts(const uint32_t *d_rec, const int32_t *d_dst, INT n_records, INT cache_rows, INT rel_total, INT dwords, INT dim,
+                              int32_t *d_counts, void *stream);
 
 /* Device-native link prediction for test triples [first, first+count) (replaces the loop
  * distribute_training.py:465-590: getTailBatch -> sess.run(predict) -> testTail, and the head side when

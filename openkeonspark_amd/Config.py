@@ -276,13 +276,10 @@ class Config(object):
             self._beta1_power = np.float32(self.adam_beta1)
             self._beta2_power = np.float32(self.adam_beta2)
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
-        self._tab_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._tables])
-        self._grad_ptrs = _lib.table_ptrs([g.data_ptr() for g in self._grads])
-        self._numel = (ctypes.c_int64 * _lib.KGE_MAX_TABLES)(*[t.numel() for t in self._tables])
-        if self._adam:
-            self._adam_m_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._adam_m])
-            self._adam_v_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._adam_v])
+        self._refresh_pointers()
+        self._dist_ready = 0
         self._dev_batch = None
+        self._dev_batch2 = None
         self._side_stream = None
         self._prefetched = None
         # None = automatic: off at 1 GPU (measured: the sampler then competes with segsum/apply for the same CUs),
@@ -320,6 +317,97 @@ class Config(object):
         first = ctypes.c_int64(0)
         self._n_local = self.lib.kge_slice_positions(self.batch_size, lo, hi, ctypes.byref(first))
         self._first_pos = first.value
+        if self.world_size > 1 and self.trainModel is not None and getattr(self, "_dist_ready", 0) != self.world_size:
+            if self.sparse_rows:
+                self._setup_shards()
+            else:
+                self._setup_flat_buffers()
+            self._dist_ready = self.world_size
+
+    def _refresh_pointers(self):
+        self._tab_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._tables])
+        self._grad_ptrs = _lib.table_ptrs([g.data_ptr() for g in self._grads])
+        self._numel = (ctypes.c_int64 * _lib.KGE_MAX_TABLES)(*[t.numel() for t in self._tables])
+        if self._adam:
+            self._adam_m_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._adam_m])
+            self._adam_v_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._adam_v])
+
+    def _setup_flat_buffers(self):
+        """Data-parallel layout of the dense path: all tables in ONE flat fp32 buffer cut into world_size equal chunks,
+        rank g owning chunk g.  Per step the gradient image is reduce-scattered, the optimizer runs on the owned chunk only
+        and the updated chunks are all-gathered (what the reference's ps tasks do for their share of the variables,
+        distribute_training.py:193-196).  TransE: the chunk is a whole number of rows of the [(E+R), D] row space, because
+        the sign-count update needs whole rows; other models: any 4-element boundary."""
+        import torch
+        from .parallel import chunk_size
+        W = self.world_size
+        names = list(self.trainModel.table_names)
+        numels = [t.numel() for t in self._tables]
+        if self.use_counts:     # ent_embeddings then rel_embeddings, back to back: rows of one [(E+R), D] space
+            D = self.hidden_size
+            chunk_rows = chunk_size(self.entTotal + self.relTotal, W, 4)
+            chunk = chunk_rows * D
+            offs = [0, numels[0]]
+            self._own_rows = (self.rank * chunk_rows, min((self.rank + 1) * chunk_rows, self.entTotal + self.relTotal))
+        else:
+            offs, off = [], 0
+            for n in numels:
+                offs.append(off)
+                off += -(-n // 64) * 64
+            chunk = chunk_size(off, W, 4)
+        total = chunk * W
+        dev = self._tables[0].device
+        flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        flat_m = torch.zeros(total, dtype=torch.float32, device=dev) if self._adam else None
+        flat_v = torch.zeros(total, dtype=torch.float32, device=dev) if self._adam else None
+        for i, name in enumerate(names):
+            shape = self._tables[i].shape
+            view = flat_p[offs[i]:offs[i] + numels[i]].view(shape)
+            view.copy_(self._tables[i])
+            self._tables[i] = view
+            self.trainModel.parameter_lists[name] = view
+            setattr(self.trainModel, name, view)
+            self._grads[i] = flat_g[offs[i]:offs[i] + numels[i]].view(shape)
+            if self._adam:
+                for flat, slots in ((flat_m, self._adam_m), (flat_v, self._adam_v)):
+                    v = flat[offs[i]:offs[i] + numels[i]].view(shape)
+                    v.copy_(slots[i])
+                    slots[i] = v
+        self._flat_p, self._flat_g, self._flat_m, self._flat_v = flat_p, flat_g, flat_m, flat_v
+        self._chunk = chunk
+        self._own = (self.rank * chunk, (self.rank + 1) * chunk)
+        self._grads_own = torch.zeros(chunk, dtype=torch.float32, device=dev)
+        if self.use_counts:
+            self._counts = torch.zeros((chunk_rows * W, self.hidden_size), dtype=torch.int32, device=dev)
+            self._counts_own = torch.zeros((chunk_rows, self.hidden_size), dtype=torch.int32, device=dev)
+        self._opt_state_synced = True
+        self._refresh_pointers()
+
+    def _setup_shards(self):
+        """Table-sharded sparse mode (config #5 on N GPUs): rank g keeps the entity rows [g*chunk, (g+1)*chunk) only; the
+        relation table stays replicated.  The shard is cut from the table this rank initialised with the common seed, so
+        the union of the shards is the single-process table."""
+        import torch
+        from .parallel import chunk_size
+        if self.hidden_size % 4:
+            raise KgeError("the table-sharded sparse mode needs an embedding width that is a multiple of 4")
+        if self.world_size > 64:
+            raise KgeError("the table-sharded sparse mode supports up to 64 ranks")
+        W, g, E, D = self.world_size, self.rank, self.entTotal, self.hidden_size
+        chunk = chunk_size(E, W)
+        lo, hi = min(g * chunk, E), min((g + 1) * chunk, E)
+        full = self._tables[0]
+        shard = torch.zeros((chunk, D), dtype=torch.float32, device=full.device)
+        if hi > lo:
+            shard[:hi - lo].copy_(full[lo:hi])
+        self._tables[0] = shard
+        self.trainModel.parameter_lists["ent_embeddings"] = shard
+        self.trainModel.ent_embeddings = shard
+        del full
+        torch.cuda.empty_cache()
+        self._shard = dict(chunk=chunk, lo=lo, hi=hi)
+        self._refresh_pointers()
 
     def _stream(self):
         import torch
@@ -381,21 +469,50 @@ class Config(object):
                                                  self.negative_ent + self.negative_rel, stride, denom,
                                                  self._grad_ptrs, self._loss.data_ptr(), self._stream()), self.lib)
 
-    def apply_gradients(self):
-        """GradientDescentOptimizer / AdamOptimizer on the summed gradients (distribute_training.py:95-101)."""
+    def _adam_lr_t(self):
+        f = np.float32
+        return f(f(self.alpha) * np.sqrt(f(1) - self._beta2_power, dtype=np.float32) / (f(1) - self._beta1_power))
+
+    def _adam_advance(self):
+        f = np.float32
+        self._beta1_power = f(self._beta1_power * f(self.adam_beta1))
+        self._beta2_power = f(self._beta2_power * f(self.adam_beta2))
+
+    def apply_gradients(self, own=False):
+        """GradientDescentOptimizer / AdamOptimizer on the summed gradients (distribute_training.py:95-101).
+        own=True (data-parallel): on this rank's chunk of the flat parameter buffer only, from its reduce-scattered
+        gradient chunk."""
         st = self._stream()
-        if self._adam:
-            f = np.float32
-            lr_t = f(f(self.alpha) * np.sqrt(f(1) - self._beta2_power, dtype=np.float32) / (f(1) - self._beta1_power))
+        if own:
+            lo, n = self._own[0], self._chunk
+            p, g = self._flat_p.data_ptr() + 4 * lo, self._grads_own.data_ptr()
+            if self._adam:
+                _lib.check(self.lib.kge_adam_update(p, self._flat_m.data_ptr() + 4 * lo, self._flat_v.data_ptr() + 4 * lo, g, n,
+                                                    float(self._adam_lr_t()), self.adam_beta1, self.adam_beta2,
+                                                    self.adam_epsilon, st), self.lib)
+                self._adam_advance()
+                self._opt_state_synced = False
+            else:
+                _lib.check(self.lib.kge_sgd_update(p, g, n, float(self.alpha), st), self.lib)
+        elif self._adam:
             _lib.check(self.lib.kge_adam_update_tables(len(self._tables), self._tab_ptrs, self._adam_m_ptrs, self._adam_v_ptrs,
-                                                       self._grad_ptrs, self._numel, float(lr_t), self.adam_beta1,
+                                                       self._grad_ptrs, self._numel, float(self._adam_lr_t()), self.adam_beta1,
                                                        self.adam_beta2, self.adam_epsilon, st), self.lib)
-            self._beta1_power = f(self._beta1_power * f(self.adam_beta1))
-            self._beta2_power = f(self._beta2_power * f(self.adam_beta2))
+            self._adam_advance()
         else:
             _lib.check(self.lib.kge_sgd_update_tables(len(self._tables), self._tab_ptrs, self._grad_ptrs, self._numel,
                                                       float(self.alpha), st), self.lib)
         self.global_step += 1
+
+    def sync_optimizer_state(self):
+        """Data-parallel Adam keeps m and v current on their owner only; gather them before they are read as whole tables
+        (checkpoints)."""
+        if self.world_size > 1 and self._adam and not self.sparse_rows and not getattr(self, "_opt_state_synced", True):
+            from .parallel import all_gather_chunks
+            lo, hi = self._own
+            all_gather_chunks(self._flat_m, self._flat_m[lo:hi], self._pg)
+            all_gather_chunks(self._flat_v, self._flat_v[lo:hi], self._pg)
+            self._opt_state_synced = True
 
     def train_step(self, batch_h=None, batch_t=None, batch_r=None, batch_y=None, sync=True):
         '''
@@ -422,7 +539,10 @@ class Config(object):
         # (same decision on every rank: it depends on the global batch only)
         big = (self.batch_size if batch_h is None else n_pos) * (3 + n_neg) >= self.counts_min_records * self.world_size
         if self.sparse_rows:
-            self._sparse_step(dev, n_pos, stride, denom, check_shape=batch_h is not None)
+            if self.world_size > 1:
+                self._sharded_step(dev, n_pos, stride, denom)
+            else:
+                self._sparse_step(dev, n_pos, stride, denom, check_shape=batch_h is not None)
             if batch_h is None and self.prefetch_sampling:
                 self._prefetch_next_batch()
         elif self.use_counts and big:
@@ -430,17 +550,28 @@ class Config(object):
             if batch_h is None and self.prefetch_sampling:
                 self._prefetch_next_batch()
             if self.world_size > 1:
-                from .parallel import allreduce_gradients
-                allreduce_gradients([self._counts, self._loss], self._pg)  # int32 SUM: exact
-            self.apply_counts(denom)
+                # int32 SUM is exact: rank g receives the summed counts of ITS rows, updates them, and the updated rows go round
+                from .parallel import reduce_scatter_sum, allreduce_sum, all_gather_chunks
+                reduce_scatter_sum(self._counts_own.view(-1), self._counts.view(-1), self._pg)
+                allreduce_sum([self._loss], self._pg)
+                self._counts.zero_()
+                self.apply_counts(denom, own=True)
+                all_gather_chunks(self._flat_p, self._flat_p[self._own[0]:self._own[1]], self._pg)
+            else:
+                self.apply_counts(denom)
         else:
             self.forward_backward(dev, n_pos, stride, denom)
             if batch_h is None and self.prefetch_sampling:
                 self._prefetch_next_batch()
             if self.world_size > 1:
-                from .parallel import allreduce_gradients
-                allreduce_gradients(self._grads + [self._loss], self._pg)
-            self.apply_gradients()
+                from .parallel import reduce_scatter_sum, allreduce_sum, all_gather_chunks
+                reduce_scatter_sum(self._grads_own, self._flat_g, self._pg)
+                allreduce_sum([self._loss], self._pg)
+                self._flat_g.zero_()
+                self.apply_gradients(own=True)
+                all_gather_chunks(self._flat_p, self._flat_p[self._own[0]:self._own[1]], self._pg)
+            else:
+                self.apply_gradients()
         self.trainModel.loss = self._loss
         return float(self._loss.item()) if sync else self._loss
 
@@ -505,6 +636,112 @@ class Config(object):
                 self.lib)
         self.global_step += 1
 
+    def _desc_with(self, **fields):
+        """A copy of the model descriptor with some fields replaced (row spaces of a cache / a shard)."""
+        d = self._desc
+        vals = {name: getattr(d, name) for name, _ in d._fields_}
+        vals.update(fields)
+        return _lib.ModelDesc(*[vals[name] for name, _ in d._fields_])
+
+    def _shard_buffers(self, M, n_recv_rows, n_recv_rec):
+        """Workspace of the sharded step, grown geometrically (receive sizes vary from step to step)."""
+        import torch
+        D, W, dev = self.hidden_size, self.world_size, self.device
+        dw = int(self.lib.kge_transe_record_dwords(ctypes.byref(self._desc)))
+        b = self._sparse_buf if isinstance(self._sparse_buf, dict) and self._sparse_buf.get("sharded") else dict(sharded=True, M=0, rr=0, rc=0)
+        i32 = torch.int32
+        if M > b["M"] or "req" not in b:
+            cap = max(int(M * 1.25), 64)
+            b.update(M=cap, req=torch.empty(cap, dtype=i32, device=dev), slot_of=torch.empty(cap, dtype=i32, device=dev),
+                     send_ids=torch.empty(cap, dtype=i32, device=dev), cache=torch.empty((cap, D), dtype=torch.float32, device=dev),
+                     rec=torch.empty((cap, dw), dtype=i32, device=dev), dst=torch.empty(cap, dtype=i32, device=dev),
+                     ids2=torch.empty(cap, dtype=i32, device=dev), slot_of2=torch.empty(cap, dtype=i32, device=dev),
+                     send_rows2=torch.empty(cap, dtype=i32, device=dev), send_rec=torch.empty((cap, dw), dtype=i32, device=dev),
+                     counts=torch.zeros(W, dtype=i32, device=dev), cursor=torch.zeros(W, dtype=i32, device=dev),
+                     rel_counts=torch.zeros((self.relTotal, D), dtype=i32, device=dev),
+                     rel_rows=torch.arange(self.entTotal, self.entTotal + self.relTotal, dtype=i32, device=dev),
+                     n_rel=torch.full((1,), self.relTotal, dtype=i32, device=dev), n_rows=torch.zeros(1, dtype=i32, device=dev), dw=dw)
+        if n_recv_rows > b["rr"]:
+            cap = max(int(n_recv_rows * 1.25), 64)
+            b.update(rr=cap, recv_ids=torch.empty(cap, dtype=i32, device=dev), rows_out=torch.empty((cap, D), dtype=torch.float32, device=dev))
+        if n_recv_rec > b["rc"]:
+            cap = max(int(n_recv_rec * 1.25), 64)
+            b.update(rc=cap, recv_rows2=torch.empty(cap, dtype=i32, device=dev), recv_rec=torch.empty((cap, dw), dtype=i32, device=dev),
+                     rows=torch.empty(cap, dtype=i32, device=dev), row_counts=torch.empty((cap, D), dtype=i32, device=dev))
+        self._sparse_buf = b
+        return b
+
+    def _sharded_step(self, dev_batch, n_pos, stride, denom):
+        """Sparse-row TransE step on a SHARDED entity table (world_size > 1): every stage is O(local batch).
+        request ids -> all-to-all -> owners gather rows -> all-to-all -> emit int8 records against the fetched rows ->
+        all-to-all (row id, record) -> owners sort / sum / apply their rows; relation counts all-reduced (csrc/shard.hip).
+        Integer sums and one per-row update formula: the union of the shards equals the single-process table bit for bit."""
+        import torch
+        from . import parallel as par
+        L, st, W, D, pg = self.lib, self._stream(), self.world_size, self.hidden_size, self._pg
+        n_neg = self.negative_ent + self.negative_rel
+        sh = self._shard
+        chunk = sh["chunk"]
+        M = n_pos * (3 + n_neg)
+        b = self._shard_buffers(M, 0, 0)
+        dw = b["dw"]
+        h, t, r = dev_batch[0], dev_batch[1], dev_batch[2]
+        bstride = dev_batch.shape[1] // (1 + n_neg)
+        # 1. which entity rows does this slice touch, and who owns them
+        _lib.check(L.kge_shard_requests(h.data_ptr(), t.data_ptr(), r.data_ptr(), n_pos, n_neg, bstride, b["req"].data_ptr(), st), L)
+        _lib.check(L.kge_shard_count(b["req"].data_ptr(), M, chunk, W, b["counts"].data_ptr(), st), L)
+        send, recv = par.exchange_counts(b["counts"], pg)
+        h_counts = (ctypes.c_int64 * W)(*send)
+        _lib.check(L.kge_shard_scatter(b["req"].data_ptr(), M, chunk, W, h_counts, b["cursor"].data_ptr(), b["send_ids"].data_ptr(),
+                                       b["slot_of"].data_ptr(), st), L)
+        n_send, n_recv = sum(send), sum(recv)
+        b = self._shard_buffers(M, n_recv, 0)
+        # 2. ids out, rows back
+        par.all_to_all_rows(b["recv_ids"], b["send_ids"], recv, send, pg)
+        _lib.check(L.kge_shard_gather_rows(self._tables[0].data_ptr(), b["recv_ids"].data_ptr(), n_recv, sh["lo"], chunk, D,
+                                           b["rows_out"].data_ptr(), st), L)
+        par.all_to_all_rows(b["cache"], b["rows_out"], send, recv, pg)
+        # 3. the unchanged emit kernel over the fetched rows: the batch in terms of cache slots
+        if self._dev_batch2 is None or self._dev_batch2.shape != dev_batch.shape:
+            self._dev_batch2 = torch.zeros_like(dev_batch)
+        h2, t2 = self._dev_batch2[0], self._dev_batch2[1]
+        _lib.check(L.kge_shard_remap_batch(h.data_ptr(), t.data_ptr(), n_pos, n_neg, bstride, b["slot_of"].data_ptr(), h2.data_ptr(),
+                                           t2.data_ptr(), st), L)
+        desc2 = self._desc_with(ent_total=max(n_send, 1))
+        _lib.check(L.kge_transe_emit_records(ctypes.byref(desc2), b["cache"].data_ptr(), self._tables[1].data_ptr(), h2.data_ptr(),
+                                             t2.data_ptr(), r.data_ptr(), n_pos, n_neg, bstride, denom, b["rec"].data_ptr(),
+                                             b["dst"].data_ptr(), None, None, self._loss.data_ptr(), st), L)
+        # 4. relation rows: dense int32 image, all-reduced (the relation table is replicated)
+        b["rel_counts"].zero_()
+        _lib.check(L.kge_shard_relation_counts(b["rec"].data_ptr(), b["dst"].data_ptr(), M, desc2.ent_total, self.relTotal, dw, D,
+                                               b["rel_counts"].data_ptr(), st), L)
+        par.allreduce_sum([b["rel_counts"], self._loss], pg)
+        # 5. entity records to their owners
+        _lib.check(L.kge_shard_record_ids(b["dst"].data_ptr(), M, n_send, b["send_ids"].data_ptr(), b["ids2"].data_ptr(), st), L)
+        _lib.check(L.kge_shard_count(b["ids2"].data_ptr(), M, chunk, W, b["counts"].data_ptr(), st), L)
+        send2, recv2 = par.exchange_counts(b["counts"], pg)
+        h_counts2 = (ctypes.c_int64 * W)(*send2)
+        _lib.check(L.kge_shard_scatter(b["ids2"].data_ptr(), M, chunk, W, h_counts2, b["cursor"].data_ptr(), b["send_rows2"].data_ptr(),
+                                       b["slot_of2"].data_ptr(), st), L)
+        _lib.check(L.kge_shard_pack_records(b["rec"].data_ptr(), b["slot_of2"].data_ptr(), M, dw, b["send_rec"].data_ptr(), st), L)
+        n_recv2 = sum(recv2)
+        b = self._shard_buffers(M, n_recv, n_recv2)
+        par.all_to_all_rows(b["recv_rows2"], b["send_rows2"], recv2, send2, pg)
+        par.all_to_all_rows(b["recv_rec"], b["send_rec"], recv2, send2, pg)
+        # 6. owner: sort by row, segmented sum, SGD on the touched rows of the shard
+        if n_recv2 > 0:
+            b["recv_rows2"][:n_recv2].sub_(sh["lo"])
+            desc3 = self._desc_with(ent_total=chunk, rel_total=0)
+            _lib.check(L.kge_transe_reduce_apply_records_sgd(
+                ctypes.byref(desc3), b["recv_rec"].data_ptr(), b["recv_rows2"].data_ptr(), n_recv2, self._tables[0].data_ptr(),
+                self._tables[1].data_ptr(), b["rows"].data_ptr(), b["row_counts"].data_ptr(), b["n_rows"].data_ptr(), denom,
+                float(self.alpha), st), L)
+        # 7. every rank applies the identical relation update from the all-reduced counts
+        _lib.check(L.kge_transe_apply_rows_sgd(ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(),
+                                               b["rel_rows"].data_ptr(), b["rel_counts"].data_ptr(), b["n_rel"].data_ptr(),
+                                               self.relTotal, denom, float(self.alpha), st), L)
+        self.global_step += 1
+
     def sparse_row_gradients(self):
         """(rows int32[n], counts int32[n, D]) of the last sparse step: the touched rows (entity rows first, relation
         rows offset by entTotal) and their integer sign counts (complete only with sparse_fused = False)."""
@@ -521,22 +758,26 @@ class Config(object):
             self.negative_ent + self.negative_rel, stride, denom, self._counts.data_ptr(),
             resid[0], resid[1], self._loss.data_ptr(), self._stream()), self.lib)
 
-    def apply_counts(self, denom):
+    def apply_counts(self, denom, own=False):
         """Normalise-backward on the summed counts + SGD / TF1 Adam, both tables in one launch
-        (distribute_training.py:95-101)."""
+        (distribute_training.py:95-101).  own=True (data-parallel): this rank's rows of the [(E+R), D] row space only,
+        from its reduce-scattered chunk of the count image."""
         st = self._stream()
-        f = np.float32
-        if self._adam:
-            lr = float(f(f(self.alpha) * np.sqrt(f(1) - self._beta2_power, dtype=np.float32) / (f(1) - self._beta1_power)))
+        lr = float(self._adam_lr_t()) if self._adam else float(self.alpha)
+        m_ptrs = self._adam_m_ptrs if self._adam else None
+        v_ptrs = self._adam_v_ptrs if self._adam else None
+        if own:
+            _lib.check(self.lib.kge_transe_apply_counts_range(
+                ctypes.byref(self._desc), self._tab_ptrs, m_ptrs, v_ptrs, self._counts_own.data_ptr(), self._grad_ptrs,
+                self._own_rows[0], self._own_rows[1], denom, 1 if self._adam else 0, lr, self.adam_beta1, self.adam_beta2,
+                self.adam_epsilon, st), self.lib)
+            self._opt_state_synced = not self._adam
         else:
-            lr = float(self.alpha)
-        _lib.check(self.lib.kge_transe_apply_counts_tables(
-            ctypes.byref(self._desc), self._tab_ptrs, self._adam_m_ptrs if self._adam else None,
-            self._adam_v_ptrs if self._adam else None, self._counts.data_ptr(), self._grad_ptrs, denom,
-            1 if self._adam else 0, lr, self.adam_beta1, self.adam_beta2, self.adam_epsilon, st), self.lib)
+            _lib.check(self.lib.kge_transe_apply_counts_tables(
+                ctypes.byref(self._desc), self._tab_ptrs, m_ptrs, v_ptrs, self._counts.data_ptr(), self._grad_ptrs, denom,
+                1 if self._adam else 0, lr, self.adam_beta1, self.adam_beta2, self.adam_epsilon, st), self.lib)
         if self._adam:
-            self._beta1_power = f(self._beta1_power * f(self.adam_beta1))
-            self._beta2_power = f(self._beta2_power * f(self.adam_beta2))
+            self._adam_advance()
         self.global_step += 1
 
     def _check_ids(self, host):
@@ -724,9 +965,19 @@ class Config(object):
     def get_parameter_lists(self):
         return self.trainModel.parameter_lists
 
+    def _sharded(self, var_name):
+        return self.world_size > 1 and getattr(self, "sparse_rows", False) and var_name == "ent_embeddings" and hasattr(self, "_shard")
+
     def get_parameters_by_name(self, var_name):
         if var_name in self.trainModel.parameter_lists:
-            return self.trainModel.parameter_lists[var_name].detach().cpu().numpy()
+            t = self.trainModel.parameter_lists[var_name]
+            if self._sharded(var_name):   # collective: every rank must call it (the shards are gathered; small tables only)
+                import torch
+                from .parallel import all_gather_chunks
+                full = torch.empty((self._shard["chunk"] * self.world_size, t.shape[1]), dtype=t.dtype, device=t.device)
+                all_gather_chunks(full.view(-1), t.reshape(-1), self._pg)
+                return full[:self.entTotal].cpu().numpy()
+            return t.detach().cpu().numpy()
         return None
 
     def get_parameters(self, mode="numpy"):
@@ -748,7 +999,12 @@ class Config(object):
         import torch
         if var_name in self.trainModel.parameter_lists:
             dst = self.trainModel.parameter_lists[var_name]
-            dst.copy_(torch.as_tensor(np.asarray(tensor, dtype=np.float32)).reshape(dst.shape))
+            src = torch.as_tensor(np.asarray(tensor, dtype=np.float32))
+            if self._sharded(var_name):
+                lo, hi = self._shard["lo"], self._shard["hi"]
+                dst[:hi - lo].copy_(src.reshape(self.entTotal, -1)[lo:hi])
+            else:
+                dst.copy_(src.reshape(dst.shape))
 
     def set_parameters(self, lists):
         for i in lists:
@@ -758,12 +1014,36 @@ class Config(object):
         """Current contents of the dense gradient accumulators (zero between steps)."""
         return {n: g.detach().cpu().numpy() for n, g in zip(self.trainModel.table_names, self._grads)}
 
-    def get_stream_states(self):
-        """rng stream states of the virtual sampler threads (next_random[], Random.h:6).  With sampling one
-        step ahead (prefetch_sampling) the states are those AFTER the prefetched batch was drawn."""
+    def get_stream_states(self, before_prefetch=False):
+        """rng stream states of the virtual sampler threads (next_random[], Random.h:6).  With sampling one step ahead
+        (prefetch_sampling) the device states are those AFTER the prefetched batch was drawn; before_prefetch=True rewinds
+        them by that one batch (what a checkpoint must store so that a resumed run trains on the prefetched batch too)."""
         import torch
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         out = np.zeros(self.workThreads, dtype=np.uint64)
         _lib.check(self.lib.kge_get_stream_states(out.ctypes.data, self.workThreads), self.lib)
+        if before_prefetch and getattr(self, "_prefetched", None) is not None:
+            from .parallel import slice_positions
+            draws = 1 + 2 * self.negative_ent + self.negative_rel          # rng draws per positive (Base.cpp:101-139)
+            for i in range(self.workThreads):
+                _, cnt = slice_positions(self.batch_size, self.workThreads, i, i + 1)
+                out[i] = np.uint64(lcg_jump(int(out[i]), -cnt * draws))
         return out
+
+
+LCG_A, LCG_C, MASK64 = 25214903917, 11, (1 << 64) - 1   # Random.h:16-19: x = x * 25214903917 + 11 (mod 2^64)
+
+
+def lcg_jump(state, n):
+    """The stream state n draws later (n < 0: earlier; the generator has full period 2^64, so stepping back n draws is
+    stepping forward 2^64 - n)."""
+    n %= 1 << 64
+    a, c = LCG_A, LCG_C
+    acc_a, acc_c = 1, 0
+    while n:
+        if n & 1:
+            acc_a, acc_c = (acc_a * a) & MASK64, (acc_c * a + c) & MASK64
+        a, c = (a * a) & MASK64, (c * a + c) & MASK64
+        n >>= 1
+    return (state * acc_a + acc_c) & MASK64

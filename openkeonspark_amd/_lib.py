@@ -86,6 +86,16 @@ def _declare(L):
     L.kge_transe_reduce_records.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, i64, vp, vp, vp, vp]
     L.kge_transe_apply_rows_sgd.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i64, f32, vp]
     L.kge_transe_reduce_apply_records_sgd.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, i64, vp, vp, vp, vp, vp, i64, f32, vp]
+    L.kge_transe_apply_counts_range.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i64, i64, i32, f32, f32, f32, f32, vp]
+    # table-sharded sparse path (csrc/shard.hip)
+    L.kge_shard_requests.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp]
+    L.kge_shard_count.argtypes = [vp, i64, i64, i64, vp, vp]
+    L.kge_shard_scatter.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp]
+    L.kge_shard_remap_batch.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp, vp]
+    L.kge_shard_gather_rows.argtypes = [vp, vp, i64, i64, i64, i64, vp, vp]
+    L.kge_shard_record_ids.argtypes = [vp, i64, i64, vp, vp, vp]
+    L.kge_shard_pack_records.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.kge_shard_relation_counts.argtypes = [vp, vp, i64, i64, i64, i64, i64, vp, vp]
     return L
 
 

@@ -597,6 +597,7 @@ struct ApplyArgs {
     const int32_t *row_list, *n_rows;
     float *p2, *m2, *v2, *resid2;
     long long E;
+    long long row_lo;   // dense form on a row RANGE [row_lo, rows): S points at the image of row_lo (a rank's reduce-scattered chunk)
 };
 
 template <int L, int C, bool SPARSE>
@@ -606,11 +607,11 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
     tm.lane = threadIdx.x % L;
     tm.D = a.D;
     const long long n_rows = SPARSE ? (long long)a.n_rows[0] : a.rows;
-    for (long long i = (long long)blockIdx.x * TEAMS + threadIdx.x / L; i < n_rows; i += (long long)gridDim.x * TEAMS) {
+    for (long long i = a.row_lo + (long long)blockIdx.x * TEAMS + threadIdx.x / L; i < n_rows; i += (long long)gridDim.x * TEAMS) {
         long long row = SPARSE ? (long long)a.row_list[i] : i;
         float *table = a.p, *mt = a.m, *vt = a.v, *rt = a.resid;
         if (row >= a.E) { row -= a.E; table = a.p2; mt = a.m2; vt = a.v2; rt = a.resid2; }
-        int32_t *Sp = a.S + i * a.D;
+        int32_t *Sp = a.S + (i - a.row_lo) * a.D;
         float *rp = SPARSE ? nullptr : rt + row * a.D;
         float s[C], rs[C];
         float touched = 0.f;
@@ -932,21 +933,23 @@ int kge_transe_apply_counts(float *d_p, float *d_m, float *d_v, int32_t *d_count
     return hip_check(hipGetLastError(), "apply counts launch");
 }
 
-int kge_transe_apply_counts_tables(const kge_model_desc *m, float *const d_p[2], float *const d_m[2], float *const d_v[2],
-                                   int32_t *d_counts, float *const d_resid[2], INT denom, int32_t adam, float lr, float beta1,
-                                   float beta2, float eps, void *stream_) {
+int kge_transe_apply_counts_range(const kge_model_desc *m, float *const d_p[2], float *const d_m[2], float *const d_v[2],
+                                  int32_t *d_counts_chunk, float *const d_resid[2], INT row_lo, INT row_hi, INT denom, int32_t adam,
+                                  float lr, float beta1, float beta2, float eps, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_apply_counts_tables: no usable HIP device");
-    if (!m || !d_p || !d_p[0] || !d_p[1] || !d_counts || !d_resid || !d_resid[0] || !d_resid[1] || denom <= 0)
-        return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_counts_tables: bad arguments");
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_apply_counts: no usable HIP device");
+    if (!m || !d_p || !d_p[0] || !d_p[1] || !d_counts_chunk || !d_resid || !d_resid[0] || !d_resid[1] || denom <= 0)
+        return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_counts_tables/_range: bad arguments");
     if (adam && (!d_m || !d_v || !d_m[0] || !d_m[1] || !d_v[0] || !d_v[1]))
-        return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_counts_tables: Adam needs the moment tables");
-    const long long rows = m->ent_total + m->rel_total;
+        return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_counts_tables/_range: Adam needs the moment tables");
+    const long long all_rows = m->ent_total + m->rel_total;
+    if (row_lo < 0 || row_hi > all_rows) return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_counts_range: row range outside the tables");
+    const long long rows = row_hi - row_lo;
     if (rows <= 0) return KGE_OK;
     ApplyArgs a = {};
     a.p = d_p[0]; a.p2 = d_p[1]; a.resid = d_resid[0]; a.resid2 = d_resid[1];
     if (adam) { a.m = d_m[0]; a.m2 = d_m[1]; a.v = d_v[0]; a.v2 = d_v[1]; }
-    a.S = d_counts; a.rows = rows; a.E = m->ent_total; a.D = m->ent_dim;
+    a.S = d_counts_chunk; a.rows = row_hi; a.row_lo = row_lo; a.E = m->ent_total; a.D = m->ent_dim;
     a.unit = 1.0f / (float)denom; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.adam = adam;
     const int D = m->ent_dim;
 #define KGE_APPLY2(LL, CC)                                                                                  \
@@ -958,6 +961,14 @@ int kge_transe_apply_counts_tables(const kge_model_desc *m, float *const d_p[2],
     KGE_SHAPE_DISPATCH(D, KGE_APPLY2)
 #undef KGE_APPLY2
     return hip_check(hipGetLastError(), "apply counts launch");
+}
+
+int kge_transe_apply_counts_tables(const kge_model_desc *m, float *const d_p[2], float *const d_m[2], float *const d_v[2],
+                                   int32_t *d_counts, float *const d_resid[2], INT denom, int32_t adam, float lr, float beta1,
+                                   float beta2, float eps, void *stream_) {
+    if (!m) return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_counts_tables: bad arguments");
+    return kge_transe_apply_counts_range(m, d_p, d_m, d_v, d_counts, d_resid, 0, m->ent_total + m->rel_total, denom, adam, lr, beta1,
+                                         beta2, eps, stream_);
 }
 
 }  // extern "C"

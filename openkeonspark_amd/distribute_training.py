@@ -119,7 +119,9 @@ def get_last_step(output_path):
 
 def checkpoint_arrays(con):
     """Variables under the reference's names, Adam slots as `<var>/Adam`, `<var>/Adam_1`
-    (main_spark.py:74-98), plus the optimiser scalars and the sampler's rng streams."""
+    (main_spark.py:74-98), plus the optimiser scalars and the sampler's rng streams.  COLLECTIVE in data-parallel
+    runs (owner-kept Adam slots and sharded tables are gathered): every rank calls it, rank 0 writes."""
+    con.sync_optimizer_state()
     out = dict(con.get_parameters())
     if con._adam:
         for name, m, v in zip(con.trainModel.table_names, con._adam_m, con._adam_v):
@@ -128,15 +130,20 @@ def checkpoint_arrays(con):
         out["beta1_power"] = np.float32(con._beta1_power)
         out["beta2_power"] = np.float32(con._beta2_power)
     out["global_step"] = np.int64(con.global_step)
-    out["rng_streams"] = con.get_stream_states()
+    # with sampling one step ahead the device streams are one batch further than the training: store the states the
+    # NEXT step's batch starts from, so that a resumed run trains on exactly the batches an uninterrupted one would
+    out["rng_streams"] = con.get_stream_states(before_prefetch=True)
     return out
 
 
-def save_checkpoint(con, output_path, max_to_keep=10):
+def save_checkpoint(con, output_path, max_to_keep=10, write=True):
+    arrays = checkpoint_arrays(con)
+    if not write:
+        return None
     os.makedirs(output_path, exist_ok=True)
     step = con.global_step
     base = os.path.join(output_path, "model.ckpt-%d" % step)
-    np.savez(base + ".npz", **{k.replace("/", "__"): v for k, v in checkpoint_arrays(con).items()})
+    np.savez(base + ".npz", **{k.replace("/", "__"): v for k, v in arrays.items()})
     with open(os.path.join(output_path, "checkpoint"), "w") as f:
         f.write('model_checkpoint_path: "%s"\n' % base)
     kept = sorted(glob.glob(os.path.join(output_path, "model.ckpt-*.npz")),
@@ -160,12 +167,13 @@ def grow_table(table, rows, rng, zeros=False):
     return np.concatenate([table, new], axis=0)
 
 
-def restore_checkpoint(con, path, allow_growth=True):
+def restore_checkpoint(con, path, allow_growth=True, arrays=None):
     """Load a checkpoint into an initialised Config (after set_model_and_session).  If the dataset
     gained entities since the checkpoint was written, entity tables are grown as the reference's
-    `update_entities_and_model` does."""
+    `update_entities_and_model` does.  `arrays`: the checkpoint's contents when they were read elsewhere
+    (rank 0 reads the file and broadcasts it: the other ranks need not see the output directory)."""
     import torch
-    z = {k.replace("__", "/"): v for k, v in np.load(path).items()}
+    z = arrays if arrays is not None else {k.replace("__", "/"): v for k, v in np.load(path).items()}
     rng = np.random.default_rng(getattr(con, "seed", 0) + 1)
     shapes = con.trainModel.table_shapes()
     for i, name in enumerate(con.trainModel.table_names):
@@ -186,6 +194,7 @@ def restore_checkpoint(con, path, allow_growth=True):
     if "rng_streams" in z and len(z["rng_streams"]) == con.workThreads:
         s = np.ascontiguousarray(z["rng_streams"], dtype=np.uint64)
         con.lib.kge_set_stream_states(s.ctypes.data, con.workThreads)
+        con._prefetched = None     # a batch drawn ahead belongs to the run that was interrupted
     return con.global_step
 
 
@@ -241,9 +250,17 @@ def main_fun(argv):
     con.set_model_and_session(con.model)
     if distributed:
         con.init_distributed()
-    last_global_step = get_last_step(argv.output_path) if argv.output_path else 0
+    last_global_step = get_last_step(argv.output_path) if (argv.output_path and rank == 0) else 0
+    arrays = None
+    if distributed:   # rank 0 decides: the other ranks need not see the output directory
+        box = [last_global_step, None]
+        if rank == 0 and last_global_step > 0:
+            path = os.path.join(argv.output_path, "model.ckpt-%d.npz" % last_global_step)
+            box[1] = {k.replace("__", "/"): v for k, v in np.load(path).items()}
+        dist.broadcast_object_list(box, src=0)
+        last_global_step, arrays = box
     if last_global_step > 0:
-        restore_checkpoint(con, os.path.join(argv.output_path, "model.ckpt-%d.npz" % last_global_step))
+        restore_checkpoint(con, os.path.join(argv.output_path, "model.ckpt-%d.npz" % last_global_step), arrays=arrays)
 
     if argv.mode != "train":
         if distributed:   # one contiguous slice of the test set per rank, accumulators all-reduced
@@ -272,8 +289,8 @@ def main_fun(argv):
         if rank == 0:
             print('Global step: {} Epoch: {} Batch: {} loss: {}'.format(
                 g, int((g - last_global_step) / con.nbatches), int((g - last_global_step) % con.nbatches), loss))
-        if (g - last_global_step) % con.nbatches == 0 and rank == 0 and argv.output_path:
-            save_checkpoint(con, argv.output_path, max_to_keep=patience + 5)
+        if (g - last_global_step) % con.nbatches == 0 and argv.output_path:
+            save_checkpoint(con, argv.output_path, max_to_keep=patience + 5, write=rank == 0)
         if g < iterations and g >= to_reach_step:
             while g >= to_reach_step:
                 to_reach_step += stopping_step
@@ -304,10 +321,11 @@ def main_fun(argv):
                         with open(os.path.join(argv.output_path, "stop.txt"), "w") as f:
                             f.write(str(best_step) + "\n")
                 break
-    if rank == 0 and argv.output_path:
-        save_checkpoint(con, argv.output_path, max_to_keep=patience + 5)
-        with open(os.path.join(argv.output_path, "time.txt"), "w") as f:   # main_spark.py:339-344
-            f.write(str(time.time() - t0))
+    if argv.output_path:
+        save_checkpoint(con, argv.output_path, max_to_keep=patience + 5, write=rank == 0)
+        if rank == 0:
+            with open(os.path.join(argv.output_path, "time.txt"), "w") as f:   # main_spark.py:339-344
+                f.write(str(time.time() - t0))
     if distributed:
         import torch.distributed as dist
         dist.barrier()

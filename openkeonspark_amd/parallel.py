@@ -1,16 +1,25 @@
 """Data-parallel plumbing: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
 
 The reference distributes with TF1 asynchronous parameter servers over gRPC
-(/root/reference/distribute_training.py:174-196,226-234): every worker samples the SAME batches
-(same unseeded rng) and pushes stale gradients.  Here the path is synchronous and sharded the way
-the reference's own sampler already partitions a batch (base/Base.cpp:85-92): the batch belongs to
-`workThreads` virtual threads, each with its own rng stream and output slice; rank g of G owns the
-threads [g*W/G, (g+1)*W/G).  The union over ranks is bit-identical to the single-process batch, each
-rank differentiates its slice with the GLOBAL mean denominator, and the dense summed-gradient
-accumulators are all-reduced (SUM) before every replica applies the identical update.
+(/root/reference/distribute_training.py:174-196,226-234): the variables are SHARDED over the ps tasks
+(`replica_device_setter`, :193-196), every worker samples the SAME batches (same unseeded rng) and pushes
+stale gradients.  Here the path is synchronous and every per-rank stage is O(1/N) of the global work:
 
-Collective choice: the accumulators are dense [rows, dim] tables (the deduplicated IndexedSlices
-sum), so one all-reduce per table per step; for FB15k-237-sized tables that is ~12 MB per step.
+* the batch is split the way the reference's own sampler already partitions it (base/Base.cpp:85-92):
+  `workThreads` virtual threads, each with its own rng stream and output slice; rank g of G owns the
+  threads [g*W/G, (g+1)*W/G).  The union over ranks is bit-identical to the single-process batch and each
+  rank differentiates its slice with the GLOBAL mean denominator;
+* dense tables (FB15k-237 / WN18RR sized): the summed-gradient image (int32 sign counts for TransE, fp32
+  accumulators otherwise) is REDUCE-SCATTERED, rank g applies the optimizer to its chunk of the flat
+  parameter buffer only (owner computes: no replicated Adam sweep), and the updated chunks are
+  ALL-GATHERED.  Replicas are bit-identical by construction (one owner computes every element);
+* tables too large to replicate (config #5: 50 M x 512 = 102 GB): the entity table itself is sharded by
+  row range, rows and int8 gradient records travel by ALL-TO-ALL to / from their owners
+  (Config._sharded_step, csrc/shard.hip); only the small relation table is replicated and its integer
+  count image all-reduced.
+
+The helpers below are thin wrappers over torch.distributed that also serve the `gloo` test rigs (gloo has no
+device collectives for these ops: CUDA tensors are staged through the host there, and only there).
 """
 
 
@@ -40,27 +49,6 @@ def slice_positions(batch_size, work_threads, thread_lo, thread_hi):
     return lo, hi - lo
 
 
-def allreduce_gradients(tensors, group=None):
-    """SUM all-reduce of the per-table gradient accumulators (and the loss scalar).  Launched
-    asynchronously so the tables overlap on the wire; returns when all are complete."""
-    import torch.distributed as dist
-    import os
-    if len(tensors) > 1 and tensors[0].is_cuda and dist.get_backend(group) == "nccl" and os.environ.get("KGE_NO_COALESCE") != "1":
-        # one RCCL group call: the tables and the loss scalar travel in a single fused launch instead of one
-        # latency-bound collective each
-        try:
-            with dist._coalescing_manager(group=group, device=tensors[0].device, async_ops=True) as cm:
-                for t in tensors:
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            cm.wait()
-            return
-        except (AttributeError, TypeError, RuntimeError):
-            pass
-    works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in tensors]
-    for w in works:
-        w.wait()
-
-
 def max_slice_positions(lib, batch_size, world_size, work_threads):
     """Largest number of batch positions any rank owns (Base.cpp:85-92 slices grouped by rank)."""
     import ctypes
@@ -72,16 +60,88 @@ def max_slice_positions(lib, batch_size, world_size, work_threads):
     return max(best, 1)
 
 
-def allgather_records(rec, dst, rec_all, dst_all, process_group=None):
-    """Sparse gradient exchange: every rank receives every rank's int8 sign records and their destination rows
-    (rank-major order; integer sums downstream make the result independent of that order)."""
+def chunk_size(total, world_size, align=1):
+    """Elements (or rows) per rank so that world_size chunks cover `total`, each a multiple of `align`."""
+    per = -(-int(total) // int(world_size))
+    return -(-per // align) * align
+
+
+def _host_staged(tensor, group):
+    import torch.distributed as dist
+    return tensor.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def allreduce_sum(tensors, group=None):
+    """SUM all-reduce of a few small tensors (the loss scalar, the relation count image), launched together."""
+    import torch.distributed as dist
+    works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in tensors]
+    for w in works:
+        w.wait()
+
+
+# the name the callers of round 1 used
+allreduce_gradients = allreduce_sum
+
+
+def reduce_scatter_sum(out, inp, group=None):
+    """out[chunk] = sum over ranks of inp[rank*chunk : (rank+1)*chunk]; inp has world_size * out.numel() elements."""
     import torch
     import torch.distributed as dist
-    for src, out in ((rec, rec_all), (dst, dst_all)):
-        if src.is_cuda and dist.get_backend(process_group) == "gloo":
-            # gloo has no device all-gather: stage through the host (test rigs only; RCCL gathers in HBM)
-            host = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_gather_into_tensor(host, src.cpu(), group=process_group)
-            out.copy_(host)
-        else:
-            dist.all_gather_into_tensor(out, src, group=process_group)
+    if inp.numel() != out.numel() * dist.get_world_size(group):
+        raise ValueError("reduce_scatter_sum: input must hold world_size equal chunks")
+    if _host_staged(inp, group):
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.reduce_scatter_tensor(h_out, inp.cpu(), op=dist.ReduceOp.SUM, group=group)
+        out.copy_(h_out)
+    else:
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
+
+
+def all_gather_chunks(out, inp, group=None):
+    """out = concatenation over ranks of inp (equal chunks).  `inp` may be this rank's slice of `out` (in place)."""
+    import torch
+    import torch.distributed as dist
+    if out.numel() != inp.numel() * dist.get_world_size(group):
+        raise ValueError("all_gather_chunks: output must hold world_size equal chunks")
+    if _host_staged(inp, group):
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h_out, inp.cpu(), group=group)
+        out.copy_(h_out)
+    elif dist.get_backend(group) == "gloo":
+        dist.all_gather_into_tensor(out, inp.clone(), group=group)   # gloo copies chunk by chunk: keep input and output apart
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def exchange_counts(send_counts, group=None):
+    """send_counts: int32 device tensor [world] (how many rows this rank sends to each peer).  Returns the two HOST lists
+    (send, recv): the one synchronisation point of a variable-size exchange."""
+    import torch
+    import torch.distributed as dist
+    recv = torch.empty_like(send_counts)
+    if _host_staged(send_counts, group):
+        h = send_counts.cpu()
+        h_recv = torch.empty_like(h)
+        dist.all_to_all_single(h_recv, h, group=group)
+        return h.tolist(), h_recv.tolist()
+    dist.all_to_all_single(recv, send_counts, group=group)
+    both = torch.stack([send_counts, recv]).cpu()
+    return both[0].tolist(), both[1].tolist()
+
+
+def all_to_all_rows(out, inp, recv_counts, send_counts, group=None):
+    """Variable-size all-to-all along dim 0: rows [sum(send[:p]), sum(send[:p+1])) of `inp` go to peer p; `out` receives
+    sum(recv_counts) rows, grouped by source rank.  Row payloads of any width / dtype."""
+    import torch
+    import torch.distributed as dist
+    n_out, n_in = int(sum(recv_counts)), int(sum(send_counts))
+    if out.shape[0] < n_out or inp.shape[0] < n_in:
+        raise ValueError("all_to_all_rows: buffers smaller than the split sizes")
+    o, i = out[:n_out], inp[:n_in]
+    if _host_staged(inp, group):
+        h_out = torch.empty(o.shape, dtype=o.dtype)
+        dist.all_to_all_single(h_out, i.cpu().contiguous(), list(recv_counts), list(send_counts), group=group)
+        o.copy_(h_out)
+    else:
+        dist.all_to_all_single(o, i, list(recv_counts), list(send_counts), group=group)
+    return o

@@ -21,6 +21,8 @@ def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     import openkeonspark_amd as pkg
+    if sparse:   # the sharded step emits against a per-step row cache: norms from the gathered rows in both runs
+        pkg._lib.lib().kge_set_option(b"inv_table_max_bytes", 0)
     con = pkg.Config()
     con.set_in_path(os.path.join(GOLDEN, "kg_small"))
     con.set_work_threads(8); con.set_bern(1); con.set_dimension(48); con.set_nbatches(nbatches)  # B = 600 by default
@@ -42,42 +44,50 @@ def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model_name,opt", [("TransE", "SGD"), ("TransE", "Adam"), ("TransH", "SGD")])
-def test_two_ranks_equal_single_process(tmp_path, model_name, opt):
+def _run_worlds(tmp_path, worlds, *args):
     import torch.multiprocessing as mp
     port = 29600 + os.getpid() % 1000
-    mp.start_processes(_worker, args=(1, port, str(tmp_path), model_name, opt), nprocs=1, join=True, start_method="spawn")
-    mp.start_processes(_worker, args=(2, port + 1, str(tmp_path), model_name, opt), nprocs=2, join=True, start_method="spawn")
-    one = np.load(str(tmp_path / "w1_r0.npz"))
-    r0 = np.load(str(tmp_path / "w2_r0.npz"))
-    r1 = np.load(str(tmp_path / "w2_r1.npz"))
-    assert np.array_equal(r0["states"], one["states"]) and np.array_equal(r1["states"], one["states"])
-    assert np.allclose(r0["losses"], one["losses"], rtol=2e-5, atol=0)
+    for i, w in enumerate(worlds):
+        mp.start_processes(_worker, args=(w, port + i, str(tmp_path)) + args, nprocs=w, join=True, start_method="spawn")
+    return {w: [np.load(str(tmp_path / ("w%d_r%d.npz" % (w, r)))) for r in range(w)] for w in worlds}
+
+
+@pytest.mark.parametrize("model_name,opt,world", [("TransE", "SGD", 2), ("TransE", "Adam", 2), ("TransE", "Adam", 4), ("TransH", "SGD", 2),
+                                                  ("TransD", "Adam", 4), ("TransR", "SGD", 2)])
+def test_ranks_equal_single_process(tmp_path, model_name, opt, world):
+    """Reduce-scatter of the gradient image, optimizer on the owned chunk, all-gather of the parameters: every replica
+    holds the identical tables (one owner computes each element) and they equal the single-process run -- bit for bit
+    for TransE (integer counts), to fp32 summation order for the fp32-accumulator models."""
+    res = _run_worlds(tmp_path, [1, world], model_name, opt)
+    one = res[1][0]
+    for r in res[world]:
+        assert np.array_equal(r["states"], one["states"])
+        assert np.allclose(r["losses"], one["losses"], rtol=2e-5, atol=0)
     for k in one.files:
         if k in ("losses", "states"):
             continue
-        assert np.array_equal(r0[k], r1[k]), k  # replicas apply the identical all-reduced update
-        tol = 2e-5 if opt == "SGD" else 2e-4
-        assert np.abs(r0[k] - one[k]).max() <= tol * np.abs(one[k]).max(), k
+        for r in res[world][1:]:
+            assert np.array_equal(res[world][0][k], r[k]), k
+        if model_name == "TransE":
+            assert np.array_equal(res[world][0][k], one[k]), k
+        else:
+            tol = 2e-5 if opt == "SGD" else 2e-4
+            assert np.abs(res[world][0][k] - one[k]).max() <= tol * np.abs(one[k]).max(), k
 
 
-def test_two_ranks_sparse_record_exchange(tmp_path):
-    """Sparse-row mode: the ranks all-gather their int8 records; integer sums make the replicas' tables equal
-    to the single-process tables bit for bit."""
-    import torch.multiprocessing as mp
-    port = 29700 + os.getpid() % 1000
-    mp.start_processes(_worker, args=(1, port, str(tmp_path), "TransE", "SGD", True), nprocs=1, join=True, start_method="spawn")
-    mp.start_processes(_worker, args=(2, port + 1, str(tmp_path), "TransE", "SGD", True), nprocs=2, join=True, start_method="spawn")
-    one = np.load(str(tmp_path / "w1_r0.npz"))
-    r0 = np.load(str(tmp_path / "w2_r0.npz"))
-    r1 = np.load(str(tmp_path / "w2_r1.npz"))
-    assert np.array_equal(r0["states"], one["states"]) and np.array_equal(r1["states"], one["states"])
-    assert np.allclose(r0["losses"], one["losses"], rtol=2e-5, atol=0)
-    for k in one.files:
-        if k in ("losses", "states"):
-            continue
-        assert np.array_equal(r0[k], r1[k]), k
-        assert np.array_equal(r0[k], one[k]), k
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_sharded_sparse_table(tmp_path, world):
+    """Sparse-row mode on N ranks: the entity table is SHARDED by row range, rows and int8 records travel by all-to-all
+    to / from their owners, the relation counts are all-reduced.  Integer sums and one per-row update formula: the union
+    of the shards equals the single-process tables bit for bit, the replicated relation table too."""
+    res = _run_worlds(tmp_path, [1, world], "TransE", "SGD", True)
+    one = res[1][0]
+    for r in res[world]:
+        assert np.array_equal(r["states"], one["states"])
+        assert np.allclose(r["losses"], one["losses"], rtol=2e-5, atol=0)
+        for k in one.files:
+            if k not in ("losses", "states"):
+                assert np.array_equal(r[k], one[k]), k
 
 
 def test_two_ranks_with_prefetched_sampling(tmp_path):
@@ -213,3 +223,36 @@ def test_cli_driver_under_two_ranks(tmp_path):
     assert m1.keys() == m2.keys()
     for k in m1:
         assert abs(m1[k] - m2[k]) <= 1e-12 * max(1.0, abs(m1[k])), k
+
+
+def _resume_worker(rank, world, port, out_dir, run, train_times):
+    sys.path.insert(0, ROOT)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": str(rank), "KGE_SINGLE_DEVICE": "1", "KGE_DIST_BACKEND": "gloo",
+                       "KGE_COUNTS_MIN_RECORDS": "0"})
+    import torch.distributed as dist
+    from openkeonspark_amd import distribute_training as dt
+    args = ["--input_path", os.path.join(GOLDEN, "kg_small"), "--output_path", os.path.join(out_dir, run),
+            "--embedding_dimension", "32", "--n_mini_batches", "5", "--ent_neg_rate", "3", "--alpha", "0.01",
+            "--optimizer", "Adam", "--bern_flag", "1", "--train_times", str(train_times)]
+    con = dt.main_fun(dt.parse_args(args))
+    assert con.prefetch_sampling                      # the data-parallel default: batch i+1 is drawn during step i
+    np.savez(os.path.join(out_dir, "%s_t%d_r%d.npz" % (run, train_times, rank)), step=con.global_step, **con.get_parameters())
+
+
+def test_two_rank_resume_equals_uninterrupted_run(tmp_path):
+    """Checkpoint / resume under data parallelism with sampling one step ahead: the checkpoint stores the rng states the
+    NEXT batch starts from (the prefetched batch is rewound), rank 0 reads it and broadcasts it, and the resumed run ends
+    with the tables of the uninterrupted one, bit for bit."""
+    import torch.multiprocessing as mp
+    port = 30500 + os.getpid() % 1000
+    for i, (run, times) in enumerate((("full", 4), ("split", 2), ("split", 2))):
+        mp.start_processes(_resume_worker, args=(2, port + i, str(tmp_path), run, times), nprocs=2, join=True, start_method="spawn")
+        if run == "split" and i == 1:
+            os.rename(str(tmp_path / "split_t2_r0.npz"), str(tmp_path / "split_first_r0.npz"))
+    full = np.load(str(tmp_path / "full_t4_r0.npz"))
+    first = np.load(str(tmp_path / "split_first_r0.npz"))
+    second = np.load(str(tmp_path / "split_t2_r0.npz"))
+    assert int(first["step"]) == 10 and int(second["step"]) == 20 and int(full["step"]) == 20
+    for k in full.files:
+        assert np.array_equal(second[k], full[k]), k

@@ -24,7 +24,7 @@ def _worker(rank, world, port, kg_dir, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle
-    from openkeonspark_amd.parallel import thread_range, slice_positions, allreduce_gradients
+    from openkeonspark_amd.parallel import thread_range, slice_positions, allreduce_sum as allreduce_gradients
     W, B, n, D = 8, 203, 3, 32   # 203 % 8 != 0: ragged slices
     kg = oracle.KG(kg_dir, work_threads=W, bern=1)
     bh, bt, br, _ = kg.sampling(B, n, 0)      # every rank draws the same global batch (same seeds)
@@ -65,38 +65,41 @@ def test_thread_range_requires_divisibility():
         thread_range(0, 3, 8)
 
 
-def _records_worker(rank, world, port, out_dir):
+def _collectives_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from openkeonspark_amd import _lib
-    from openkeonspark_amd.parallel import allgather_records, max_slice_positions, thread_range, slice_positions
-    lib = _lib.load()
-    W, B, dw = 6, 100, 4            # 100 % 6 != 0: ragged slices, ranks own 51 and 49 positions
-    lib.setWorkThreads(W)
-    m = max_slice_positions(lib, B, world, W)
-    lo, hi = thread_range(rank, world, W)
-    first, cnt = slice_positions(B, W, lo, hi)
-    assert cnt <= m
-    rec = torch.full((m, dw), -1, dtype=torch.int32)
-    dst = torch.full((m,), -1, dtype=torch.int32)
-    dst[:cnt] = torch.arange(first, first + cnt, dtype=torch.int32)   # record i of the global batch
-    rec[:cnt] = dst[:cnt, None] * 10 + torch.arange(dw, dtype=torch.int32)
-    rec_all = torch.empty((m * world, dw), dtype=torch.int32)
-    dst_all = torch.empty(m * world, dtype=torch.int32)
-    allgather_records(rec, dst, rec_all, dst_all)
-    np.savez(os.path.join(out_dir, "rec%d.npz" % rank), rec=rec_all.numpy(), dst=dst_all.numpy(), m=m)
+    from openkeonspark_amd import parallel as par
+    # reduce-scatter of an int32 image: rank g ends with the column sums of ITS chunk
+    chunk = 6
+    img = (torch.arange(world * chunk, dtype=torch.int32) + 1) * (rank + 1)
+    own = torch.zeros(chunk, dtype=torch.int32)
+    par.reduce_scatter_sum(own, img)
+    want = (torch.arange(world * chunk, dtype=torch.int32) + 1)[rank * chunk:(rank + 1) * chunk] * sum(range(1, world + 1))
+    assert torch.equal(own, want)
+    # all-gather in place: every rank's chunk of the flat buffer reaches every rank
+    flat = torch.full((world * chunk,), -1.0)
+    flat[rank * chunk:(rank + 1) * chunk] = torch.arange(chunk, dtype=torch.float32) + 100 * rank
+    par.all_gather_chunks(flat, flat[rank * chunk:(rank + 1) * chunk])
+    assert torch.equal(flat, torch.cat([torch.arange(chunk, dtype=torch.float32) + 100 * g for g in range(world)]))
+    # variable-size all-to-all of rows (ragged, including empty sends): rank r sends (r + p) % 3 rows to peer p
+    send = [(rank + p) % 3 for p in range(world)]
+    s_counts, r_counts = par.exchange_counts(torch.tensor(send, dtype=torch.int32))
+    assert s_counts == send and r_counts == [(p + rank) % 3 for p in range(world)]
+    rows = torch.tensor([[rank, p, i] for p in range(world) for i in range(send[p])], dtype=torch.int32).reshape(-1, 3)
+    out = torch.full((sum(r_counts) + 2, 3), -7, dtype=torch.int32)
+    got = par.all_to_all_rows(out, rows, r_counts, s_counts)
+    want = torch.tensor([[p, rank, i] for p in range(world) for i in range(r_counts[p])], dtype=torch.int32).reshape(-1, 3)
+    assert torch.equal(got, want) and int(out[sum(r_counts):].max()) == -7
+    assert par.chunk_size(10, 4) == 3 and par.chunk_size(10, 4, 4) == 4 and par.chunk_size(8, 4, 1) == 2
+    open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     dist.destroy_process_group()
 
 
-def test_record_allgather_covers_every_position_once(tmp_path):
-    """The sparse exchange: equal-sized padded record blocks, every global batch position exactly once."""
-    port = 31500 + os.getpid() % 2000
-    mp.start_processes(_records_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
-    z0, z1 = np.load(str(tmp_path / "rec0.npz")), np.load(str(tmp_path / "rec1.npz"))
-    assert int(z0["m"]) == 51
-    assert np.array_equal(z0["rec"], z1["rec"]) and np.array_equal(z0["dst"], z1["dst"])
-    live = z0["dst"] >= 0
-    assert sorted(z0["dst"][live].tolist()) == list(range(100))
-    assert np.array_equal(z0["rec"][live], z0["dst"][live][:, None] * 10 + np.arange(4))
+@pytest.mark.parametrize("world", [2, 4])
+def test_exchange_helpers_on_gloo(tmp_path, world):
+    """reduce-scatter / all-gather (dense owner-computes update) and the variable-size all-to-all (sharded sparse path)."""
+    port = 31500 + os.getpid() % 2000 + world
+    mp.start_processes(_collectives_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    assert all(os.path.exists(str(tmp_path / ("ok%d" % r))) for r in range(world))
