@@ -576,33 +576,26 @@ class Config(object):
         return float(self._loss.item()) if sync else self._loss
 
     def _sparse_step(self, dev_batch, n_pos, stride, denom, check_shape=False):
-        """Sparse-row TransE step: emit int8 records -> (all-gather over ranks) -> compact per-row counts ->
-        SGD on the touched rows.  Bitwise the same update as the dense count image (integer sums)."""
+        """Sparse-row TransE step on ONE GPU: emit int8 records -> sort by destination row -> compact per-row counts ->
+        SGD on the touched rows.  Bitwise the same update as the dense count image (integer sums).  N GPUs:
+        _sharded_step."""
         import torch
-        from .parallel import allgather_records, allreduce_gradients, max_slice_positions
         n_neg = self.negative_ent + self.negative_rel
         D = self.hidden_size
-        W = self.world_size
-        if W > 1:  # every rank contributes the same number of record slots (padding has destination -1)
-            stride = max(stride, max_slice_positions(self.lib, self.batch_size, W, self.workThreads))
         m_local = stride * (3 + n_neg)
         dw = int(self.lib.kge_transe_record_dwords(ctypes.byref(self._desc)))
         buf = self._sparse_buf
-        if buf is None or buf["m_local"] != m_local or buf["W"] != W:
+        if buf is None or buf.get("m_local") != m_local:
             dev = self.device
-            buf = dict(m_local=m_local, W=W,
+            buf = dict(m_local=m_local,
                        rec=torch.empty((m_local, dw), dtype=torch.int32, device=dev),
                        dst=torch.empty(m_local, dtype=torch.int32, device=dev),
-                       rows=torch.empty(m_local * W, dtype=torch.int32, device=dev),
-                       row_counts=torch.empty((m_local * W, D), dtype=torch.int32, device=dev),
+                       rows=torch.empty(m_local, dtype=torch.int32, device=dev),
+                       row_counts=torch.empty((m_local, D), dtype=torch.int32, device=dev),
                        n_rows=torch.zeros(1, dtype=torch.int32, device=dev))
-            if W > 1:
-                buf["rec_all"] = torch.empty((m_local * W, dw), dtype=torch.int32, device=dev)
-                buf["dst_all"] = torch.empty(m_local * W, dtype=torch.int32, device=dev)
             self._sparse_buf = buf
         st = self._stream()
         buf["dst"].fill_(-1)
-        # (the BATCH arrays keep their own, local stride; only the record slots are padded to the largest slice)
         _lib.check(self.lib.kge_transe_emit_records(
             ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(),
             dev_batch[0].data_ptr(), dev_batch[1].data_ptr(), dev_batch[2].data_ptr(), n_pos, n_neg,
@@ -614,12 +607,7 @@ class Config(object):
             if nd.value:
                 raise KgeError("sparse_rows: %d groups have negatives that are not single-slot corruptions of their "
                                "positive; train such batches with sparse_rows=False" % nd.value)
-        if W > 1:
-            allgather_records(buf["rec"], buf["dst"], buf["rec_all"], buf["dst_all"], self._pg)
-            allreduce_gradients([self._loss], self._pg)
-            rec, dst = buf["rec_all"], buf["dst_all"]
-        else:
-            rec, dst = buf["rec"], buf["dst"]
+        rec, dst = buf["rec"], buf["dst"]
         if getattr(self, "sparse_fused", True) and D % 4 == 0:
             # reduce + apply in one pass: only chunk-boundary rows go through the compact count image
             _lib.check(self.lib.kge_transe_reduce_apply_records_sgd(

@@ -20,6 +20,7 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5
+KINK_TOL = 3e-7     # |e| below this: fp32 evaluations of e = h^ + r^ - t^ (|x^| <= 1) may disagree on its sign
 
 
 def near_ties(orc, bh, bt, br, B, N, eps=2e-6):
@@ -75,14 +76,14 @@ def run_steps(con, kg, orc, B, n, alpha, steps, name, model, dims):
                 worst["grad"] = max(worst["grad"], float(diff[clean].max() / scale))
             if len(bad) or len(bad_u):
                 if kink is None:
-                    kink, n_el = near_kink_rows(model, start, bh, bt, br, B, n, dims[0], dims[1], tol=1e-6)
+                    kink, n_el = near_kink_rows(model, start, bh, bt, br, B, n, dims[0], dims[1], tol=KINK_TOL)
                     worst["kink_elems"] += n_el
                 unexplained = (set(bad.tolist()) | set(bad_u.tolist())) - kink[k]
-                assert not unexplained, (name, step, k, sorted(unexplained)[:10], "rows outside 1e-5 with no |e| < 1e-6 nearby")
+                assert not unexplained, (name, step, k, sorted(unexplained)[:10], "rows outside 1e-5 with no |e| < KINK_TOL in their group")
     assert con.get_stream_states().tolist() == kg.stream_states().tolist()
     parity_report(name, batch=B, steps=steps, loss_relerr=worst["loss"], grad_relerr_other_rows=worst["grad"],
                   grad_rows_outside_1e5=worst["grad_rows"], update_rows_outside_1e5=worst["update_rows"],
-                  elements_of_e_within_1e6_of_zero=worst["kink_elems"], near_tie_hinges=worst["ties"])
+                  elements_of_e_within_tol_of_zero=worst["kink_elems"], tol=KINK_TOL, near_tie_hinges=worst["ties"])
     assert worst["loss"] <= RTOL, worst
     assert worst["grad"] <= RTOL, worst
     # every outside row was explained above; bound their number too (a flipped element reaches the <= 6 rows of its group)
@@ -171,7 +172,8 @@ def test_config5_sparse_step_matches_oracle():
     kg.set_stream_states(con.get_stream_states())
     params = con.get_parameters()
     orc = oracle.Model("transe", E, R, D, D, margin=1.0, params=params)
-    total_bad = 0
+    from torch_ref import near_kink_rows
+    total_bad = kink_elems = 0
     for step in range(2):
         before = con.get_parameters()
         states = con.get_stream_states()
@@ -183,18 +185,22 @@ def test_config5_sparse_step_matches_oracle():
         assert abs(loss_g - loss_o) <= RTOL * abs(loss_o), (loss_g, loss_o)
         after = con.get_parameters()
         unit = 1.0 / (B * n)
+        kink, n_el = near_kink_rows("transe", before, bh, bt, br, B, n, D, D, tol=KINK_TOL)
+        kink_elems += n_el
         for k in g_o:
             g_g = before[k].astype(np.float64) - after[k].astype(np.float64)
             quantum = np.abs(before[k]).max() * 2.0 ** -23
             diff = np.abs(g_g - g_o[k])
             bad_rows = np.nonzero((diff > RTOL * np.abs(g_o[k]).max() + quantum).any(1))[0]
             total_bad += len(bad_rows)
-            # a row outside 1e-5 may only be a sign flip of an element of h^+r^-t^ within rounding of zero: one count
-            # changes by 2, i.e. the row's gradient by at most ~2*unit/|row|
+            # a row outside 1e-5 may only carry sign flips of elements of h^+r^-t^ within rounding of zero: it must be a row of
+            # such a group, and one flip changes one count by at most 2, i.e. the row's gradient by ~2*unit/|row|
+            assert not set(bad_rows.tolist()) - kink[k], (k, sorted(set(bad_rows.tolist()) - kink[k])[:10])
             min_norm = np.sqrt((before[k].astype(np.float64) ** 2).sum(1)).min()
             assert diff.max() <= 2.05 * unit / min_norm + RTOL * np.abs(g_o[k]).max() + quantum, (k, diff.max())
-    parity_report("config5 sparse rows E=200k D=512 B=50000", rows_outside_1e5=total_bad, bound_rows=8)
-    assert total_bad <= 8, total_bad
+    parity_report("config5 sparse rows E=200k D=512 B=50000", rows_outside_1e5=total_bad,
+                  elements_of_e_within_tol_of_zero=kink_elems, tol=KINK_TOL)
+    assert total_bad <= 4 * kink_elems and total_bad <= 60, (total_bad, kink_elems)
 
 
 def test_config5_full_size_properties():
