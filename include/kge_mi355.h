@@ -305,6 +305,21 @@ int kge_shard_pack_records(const uint32_t *d_rec, const int32_t *d_slot_of, INT 
 int kge_shard_relation_counts(const uint32_t *d_rec, const int32_t *d_dst, INT n_records, INT cache_rows, INT rel_total, INT dwords, INT dim,
                               int32_t *d_counts, void *stream);
 
+/* ---- Many training steps in ONE persistent launch (csrc/persist.hip): the loop body of distribute_training.py:267-283 --
+ * sampling, forward / backward, optimizer -- at the reference's own (launch-latency bound) batch sizes.  One workgroup per CU
+ * stays resident and walks n_steps steps with two XCD-hierarchical grid barriers per step; batches are bit-identical to n_steps
+ * calls of `sampling` (all workThreads streams are advanced accordingly), gradients go through fp32 atomics as in
+ * kge_forward_backward's small-step path.  TransE / TransH / TransD, embedding width <= 256, the whole batch on this GPU.
+ *   h_lr[n_steps] : HOST array, the learning rate of each step (SGD: alpha; Adam: lr_t = alpha*sqrt(1-b2^t)/(1-b1^t))
+ *   d_losses[n_steps] : DEVICE array, receives every step's loss
+ * kge_persistent_aborted: 1 if a grid barrier of the last launch gave up (a bounded spin expired); the tables are then in an
+ * unspecified intermediate state and the caller must treat the run as failed.  Synchronises. */
+int kge_train_steps_persistent(const kge_model_desc *m, float *const tables[KGE_MAX_TABLES], float *const grads[KGE_MAX_TABLES],
+                               float *const adam_m[KGE_MAX_TABLES], float *const adam_v[KGE_MAX_TABLES], INT batchSize, INT negRate,
+                               INT negRelRate, INT n_steps, int32_t adam, const float *h_lr, float beta1, float beta2, float eps,
+                               float *d_losses, void *stream);
+int kge_persistent_aborted(int32_t *flag);
+
 /* Device-native link prediction for test triples [first, first+count) (replaces the loop
  * distribute_training.py:465-590: getTailBatch -> sess.run(predict) -> testTail, and the head side when
  * test_head != 0).  h_out (HOST) receives count x 2 x 8 int64: [i][0] testTail's 8-vector, [i][1]

@@ -575,6 +575,60 @@ class Config(object):
         self.trainModel.loss = self._loss
         return float(self._loss.item()) if sync else self._loss
 
+    def persistent_supported(self):
+        """Can train_steps() run its steps inside one persistent launch (csrc/persist.hip)?  Single process, the dense
+        fp32-accumulator path of TransE / TransH / TransD at a launch-latency-bound step size."""
+        if self.world_size != 1 or self.sparse_rows or self.hidden_size > 256:
+            return False
+        if self.trainModel.model_id not in (_lib.TRANSE, _lib.TRANSH, _lib.TRANSD):
+            return False
+        n_neg = self.negative_ent + self.negative_rel
+        if self.use_counts and self.batch_size * (3 + n_neg) >= self.counts_min_records:
+            return False       # TransE at a large step: the exact integer-count pipeline is the faster path
+        slots = {_lib.TRANSE: 3 + n_neg, _lib.TRANSH: 4 + n_neg, _lib.TRANSD: 6 + 2 * n_neg}[self.trainModel.model_id]
+        return self.batch_size * slots < int(getattr(self, "persistent_max_rows", 1 << 16))
+
+    def train_steps(self, n_steps, persistent=None):
+        """`n_steps` iterations of the training loop body (distribute_training.py:267-283): sample, forward / backward,
+        update.  Returns the losses (numpy float32 [n_steps]).  Where persistent_supported(), all the steps run inside ONE
+        persistent launch; otherwise (or with persistent=False) as n_steps calls of train_step()."""
+        import torch
+        n_steps = int(n_steps)
+        if n_steps <= 0:
+            return np.zeros(0, np.float32)
+        use = self.persistent_supported() if persistent is None else bool(persistent)
+        if use and not self.persistent_supported():
+            raise KgeError("train_steps(persistent=True): this configuration has no persistent-launch path")
+        if not use:
+            out = [self.train_step(sync=False) for _ in range(n_steps)]
+            return torch.stack([o.reshape(()) for o in out]).cpu().numpy()
+        if self._prefetched is not None:
+            raise KgeError("train_steps: a batch was sampled ahead by train_step(); use one or the other in a run")
+        f = np.float32
+        lr = np.empty(n_steps, np.float32)
+        if self._adam:
+            for i in range(n_steps):
+                lr[i] = self._adam_lr_t()
+                self._adam_advance()
+        else:
+            lr[:] = f(self.alpha)
+        losses = torch.empty(n_steps, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.kge_train_steps_persistent(
+            ctypes.byref(self._desc), self._tab_ptrs, self._grad_ptrs, self._adam_m_ptrs if self._adam else None,
+            self._adam_v_ptrs if self._adam else None, self.batch_size, self.negative_ent, self.negative_rel, n_steps,
+            1 if self._adam else 0, lr.ctypes.data, self.adam_beta1, self.adam_beta2, self.adam_epsilon, losses.data_ptr(),
+            self._stream()), self.lib)
+        out = losses.cpu().numpy()          # synchronises: the launch has drained
+        flag = ctypes.c_int32(0)
+        _lib.check(self.lib.kge_persistent_aborted(ctypes.byref(flag)), self.lib)
+        if flag.value:
+            raise KgeError("persistent training launch aborted: a grid barrier did not complete (is another process holding "
+                           "compute units of this GPU?); the tables are in an intermediate state")
+        self.global_step += n_steps
+        self._loss.copy_(losses[-1:])
+        self.trainModel.loss = self._loss
+        return out
+
     def _sparse_step(self, dev_batch, n_pos, stride, denom, check_shape=False):
         """Sparse-row TransE step on ONE GPU: emit int8 records -> sort by destination row -> compact per-row counts ->
         SGD on the touched rows.  Bitwise the same update as the dense count image (integer sums).  N GPUs:

@@ -1,0 +1,85 @@
+"""Many training steps inside one persistent launch (csrc/persist.hip, Config.train_steps) against the same steps as
+separate launches and against the CPU oracle: the loop body of distribute_training.py:267-283 at the reference's own batch
+sizes (Config.py:189-210).  The batches must be bit-identical (same rng streams afterwards); gradients go through fp32
+atomics in both forms, whose order is not reproducible, so tables agree to summation-order rounding, not bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, parity_report
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def engine(path, model, dim, nbatches, n, alpha, opt="SGD", bern=0, nr=0):
+    import openkeonspark_amd as pkg
+    con = pkg.Config()
+    con.prefetch_sampling = False
+    con.set_in_path(path); con.set_work_threads(8); con.set_bern(bern); con.set_dimension(dim)
+    con.set_nbatches(nbatches); con.set_ent_neg_rate(n); con.set_rel_neg_rate(nr); con.set_alpha(alpha); con.set_margin(1.0)
+    con.set_opt_method(opt)
+    con.init()
+    con.set_model_and_session(getattr(pkg, model))
+    return con
+
+
+def update_err(got, want, start):
+    return max(np.abs((got[k].astype(np.float64) - start[k]) - (want[k].astype(np.float64) - start[k])).max()
+               / (np.abs(want[k].astype(np.float64) - start[k]).max() + 1e-30) for k in want)
+
+
+@pytest.mark.parametrize("model,graph,dim,nbatches,n,nr,opt", [
+    ("TransE", "fb", 100, 0, 1, 0, "SGD"),        # configs[0]: auto batch 2 721
+    ("TransH", "wn", 200, 0, 1, 0, "SGD"),        # configs[2]: auto batch 8 683, relation hub copies folded in the sweep
+    ("TransD", "fb", 64, 0, 2, 1, "Adam"),
+    ("TransE", "small", 50, 7, 3, 1, "Adam"),     # ragged slices (857 positives over 8 threads), dim % 4 != 0
+    ("TransH", "small", 24, 10, 2, 0, "SGD"),
+])
+def test_persistent_steps_equal_separate_launches(fb_dir, wn_dir, model, graph, dim, nbatches, n, nr, opt):
+    from openkeonspark_amd import _lib
+    path = {"fb": fb_dir, "wn": wn_dir, "small": os.path.join(GOLDEN, "kg_small")}[graph]
+    S, alpha = 12, 0.01
+    runs = []
+    for persistent in (False, True):
+        _lib.lib().kge_set_option(b"libc_rand_restart", 1)
+        con = engine(path, model, dim, nbatches, n, alpha, opt, bern=1, nr=nr)
+        assert con.persistent_supported()
+        start = con.get_parameters()
+        losses = con.train_steps(S, persistent=persistent)
+        runs.append((losses, con.get_parameters(), con.get_stream_states(), con.global_step))
+        for g in con.get_gradients().values():
+            assert not g.any()                                   # accumulators (and hub copies) end re-zeroed
+    (l0, p0, s0, g0), (l1, p1, s1, g1) = runs
+    assert g0 == g1 == S and s0.tolist() == s1.tolist()          # the same batches were drawn
+    assert np.allclose(l0, l1, rtol=2e-6, atol=0), np.abs(l0 / l1 - 1).max()
+    tol = 2e-5 if opt == "SGD" else 2e-3                         # Adam: m / (sqrt(v) + eps) amplifies rounding where v ~ 0
+    err = update_err(p1, p0, start)
+    parity_report("persistent_vs_launches[%s-%s-%s]" % (model, graph, opt), steps=S, loss_relerr=float(np.abs(l1 / l0 - 1).max()),
+                  update_relerr=err, bound=tol)
+    assert err <= tol, err
+
+
+@pytest.mark.parametrize("model,graph,dim", [("transe", "fb", 100), ("transh", "wn", 200)])
+def test_persistent_steps_match_oracle(fb_dir, wn_dir, model, graph, dim):
+    """configs[0] and configs[2] at their auto batch: S steps in one launch against S oracle steps on the oracle's own
+    batches (same rng streams): losses and tables within 1e-5 / 2e-5, rng states identical afterwards."""
+    path = fb_dir if graph == "fb" else wn_dir
+    S, alpha, n = 4, 0.01, 1
+    con = engine(path, {"transe": "TransE", "transh": "TransH"}[model], dim, 0, n, alpha)
+    kg = oracle.KG(path, work_threads=8, bern=0)
+    kg.set_stream_states(con.get_stream_states())
+    start = con.get_parameters()
+    orc = oracle.Model(model, con.entTotal, con.relTotal, dim, dim, margin=1.0, params=start)
+    B = con.batch_size
+    want = []
+    for _ in range(S):
+        bh, bt, br, _ = kg.sampling(B, n, 0)
+        want.append(orc.sgd_step(bh, bt, br, B, n, alpha))
+    got = con.train_steps(S, persistent=True)
+    assert con.get_stream_states().tolist() == kg.stream_states().tolist()
+    assert np.allclose(got, want, rtol=1e-5, atol=0), (got, want)
+    err = update_err(con.get_parameters(), orc.params, start)
+    parity_report("persistent_vs_oracle[%s]" % model, steps=S, batch=B, update_relerr=err)
+    assert err <= 5e-5, err

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(name, spec, model, dim, n, opt, nbatches, steps=200, warmup=20, bern=0):
+def run(name, spec, model, dim, n, opt, nbatches, steps=200, warmup=20, bern=0, persistent=False):
     import torch
     import openkeonspark_amd as pkg
     from openkeonspark_amd.synthetic import make_dataset
@@ -21,14 +21,23 @@ def run(name, spec, model, dim, n, opt, nbatches, steps=200, warmup=20, bern=0):
     con.set_nbatches(nbatches); con.set_ent_neg_rate(n); con.set_alpha(0.001); con.set_opt_method(opt)
     con.init()
     con.set_model_and_session(getattr(pkg, model))
-    for _ in range(warmup):
-        con.train_step(sync=False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        con.train_step(sync=False)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    if persistent:     # all the timed steps inside ONE persistent launch (csrc/persist.hip)
+        con.prefetch_sampling = False
+        con.train_steps(warmup, persistent=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        con.train_steps(steps, persistent=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    else:
+        for _ in range(warmup):
+            con.train_step(sync=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            con.train_step(sync=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     out = {"config": name, "model": model, "dim": dim, "neg": n, "opt": opt, "batch": con.batch_size,
            "positives_per_s": con.batch_size * steps / dt, "ms_per_step": dt / steps * 1e3,
            "loss": float(con._loss.item())}
@@ -60,8 +69,10 @@ if __name__ == "__main__":
             os.dup2(real, 1)
         print(res, flush=True)
     quiet(run, "#1 FB15k-237 TransE D=100 SGD n=1 auto-batch", fb, "TransE", 100, 1, "SGD", 0)
+    quiet(run, "#1 same, 1000 steps in one persistent launch", fb, "TransE", 100, 1, "SGD", 0, steps=1000, persistent=True)
     quiet(run, "#1b same, nbatches=4 (B=68028)", fb, "TransE", 100, 1, "SGD", 4)
     quiet(run, "#3 WN18RR TransH D=200 n=1 auto-batch", wn, "TransH", 200, 1, "SGD", 0)
+    quiet(run, "#3 same, 1000 steps in one persistent launch", wn, "TransH", 200, 1, "SGD", 0, steps=1000, persistent=True)
     quiet(run, "#3b WN18RR TransH D=200 n=25 nbatches=2", wn, "TransH", 200, 25, "SGD", 2)
     quiet(run, "#4 FB15k-237 TransR 200x200 n=1 auto-batch", fb, "TransR", 200, 1, "SGD", 0)
     quiet(run, "#4b FB15k-237 TransR 200x200 n=1 nbatches=8", fb, "TransR", 200, 1, "SGD", 8, steps=50)
