@@ -123,6 +123,8 @@ const char *kge_version(void);
  *   "transr_v1":         1 = TransR always on the 32x32x2 MFMA tiles, 2 = 16x16x4 tiles with the all-output-tiles
  *                        wgrad forced (test hooks; default 0 = automatic)
  *   "time_emit":         N > 0 = bracket every N-th launch of the TransE emit kernel with HIP events on its launch stream
+ *   "persist_trace":     1 = kge_train_steps_persistent stamps its phase boundaries (read with kge_persistent_trace)
+ *   "persist_threads":   threads per workgroup of the persistent launch, 1024 (default) or 512
  *   "libc_rand_restart": restart the glibc-compatible seed generator, as in a fresh process (the next
  *                        randReset then yields 1804289383, 846930886, ... again) */
 int kge_set_option(const char *name, INT value);
@@ -319,6 +321,9 @@ int kge_train_steps_persistent(const kge_model_desc *m, float *const tables[KGE_
                                INT negRelRate, INT n_steps, int32_t adam, const float *h_lr, float beta1, float beta2, float eps,
                                float *d_losses, void *stream);
 int kge_persistent_aborted(int32_t *flag);
+/* measurement hook (option "persist_trace"): workgroup 0's 100 MHz clock at the six phase boundaries of each of the first
+ * n_steps (<= 256) steps of the last launch: [sweep start, sampling start, barrier-1 arrive, barrier-1 leave, barrier-2 arrive, leave] */
+int kge_persistent_trace(uint64_t *h_out, INT n_steps);
 
 /* Device-native link prediction for test triples [first, first+count) (replaces the loop
  * distribute_training.py:465-590: getTailBatch -> sess.run(predict) -> testTail, and the head side when

@@ -600,7 +600,7 @@ class Config(object):
         if use and not self.persistent_supported():
             raise KgeError("train_steps(persistent=True): this configuration has no persistent-launch path")
         if not use:
-            out = [self.train_step(sync=False) for _ in range(n_steps)]
+            out = [self.train_step(sync=False).clone() for _ in range(n_steps)]   # (the loss scalar is one reused device buffer)
             return torch.stack([o.reshape(()) for o in out]).cpu().numpy()
         if self._prefetched is not None:
             raise KgeError("train_steps: a batch was sampled ahead by train_step(); use one or the other in a run")

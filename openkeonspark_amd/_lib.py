@@ -98,6 +98,7 @@ def _declare(L):
     L.kge_shard_relation_counts.argtypes = [vp, vp, i64, i64, i64, i64, i64, vp, vp]
     L.kge_train_steps_persistent.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, i64, i64, i64, i64, i32, vp, f32, f32, f32, vp, vp]
     L.kge_persistent_aborted.argtypes = [ctypes.POINTER(ctypes.c_int32)]
+    L.kge_persistent_trace.argtypes = [vp, i64]
     return L
 
 

@@ -116,7 +116,13 @@ struct PersistArgs {
     int W;
     int fold_k;               // relation hub copies folded by the sweep (0 = none)
     long long fold_elems;     // R * D
+    unsigned long long *trace;   // option "persist_trace": 100 MHz wall-clock stamps of workgroup 0 at the phase boundaries, 6 per step
 };
+
+constexpr int kTraceSteps = 256;
+__device__ __forceinline__ void stamp(const PersistArgs &pa, int step, int slot) {
+    if (pa.trace && blockIdx.x == 0 && threadIdx.x == 0 && step < kTraceSteps) pa.trace[step * 6 + slot] = wall_clock64();
+}
 
 // Relation-side tables whose gradient rows were spread over K hub copies (fwdbwd_group adds a group's relation rows into
 // copy b % K: same-address atomics serialise): the copies are folded and the element updated by one and the same thread
@@ -162,6 +168,7 @@ __global__ __launch_bounds__(THREADS) void persistent_steps_kernel(PersistArgs p
     const unsigned long long draws = 1ull + 2ull * pa.sm.neg + pa.sm.negrel;
     for (int step = 0; step <= pa.n_steps; step++) {
         // ---------------- phase A: update of step-1, loss of step-1, sampling of this step ----------------
+        stamp(pa, step, 0);
         if (step > 0) {
             const float lr = pa.lr[step - 1];
             if (pa.fold_k > 1) sweep_folded(pa, lr, tid, stride);
@@ -179,6 +186,7 @@ __global__ __launch_bounds__(THREADS) void persistent_steps_kernel(PersistArgs p
             }
         }
         if (step == pa.n_steps) break;
+        stamp(pa, step, 1);
         for (long long g = tid; (g >> kshift) < pa.B; g += stride) {
             const long long b = g >> kshift, k = g & ((1 << kshift) - 1);
             if (k >= kp) continue;
@@ -191,7 +199,9 @@ __global__ __launch_bounds__(THREADS) void persistent_steps_kernel(PersistArgs p
             const long long o = b + k * pa.sm.out_stride;
             pa.sm.out_h[o] = oh; pa.sm.out_t[o] = ot; pa.sm.out_r[o] = orr;
         }
+        stamp(pa, step, 2);
         if (!grid_barrier(pa.bar, bs, &ok_lds)) return;
+        stamp(pa, step, 3);
         // ---------------- phase B: forward / hinge / backward of this step's batch ----------------
         float lsum = 0.f;
         for (long long b = (long long)blockIdx.x * TEAMS + team_in_block; b < pa.B; b += (long long)gridDim.x * TEAMS)
@@ -204,7 +214,9 @@ __global__ __launch_bounds__(THREADS) void persistent_steps_kernel(PersistArgs p
             for (int i = 0; i < TEAMS; i++) s += red[i];
             pa.partials[(long long)(step & 1) * gridDim.x + blockIdx.x] = s;
         }
+        stamp(pa, step, 4);
         if (!grid_barrier(pa.bar, bs, &ok_lds)) return;
+        stamp(pa, step, 5);
     }
 }
 
@@ -214,6 +226,7 @@ int32_t *g_batch = nullptr;
 int64_t g_batch_cap = 0, g_lr_cap = 0;
 float *g_hub_rel = nullptr, *g_hub_auxr = nullptr;
 int64_t g_hub_elems = 0;
+unsigned long long *g_trace = nullptr;
 
 }  // namespace
 
@@ -335,13 +348,23 @@ extern "C" int kge_train_steps_persistent(const kge_model_desc *m, float *const 
     pa.b1 = beta1; pa.b2 = beta2; pa.eps = eps;
     pa.lr = g_lr; pa.losses = d_losses; pa.partials = g_partials; pa.bar = g_bar;
     pa.B = B; pa.W = (int)W;
-    constexpr int THREADS = 1024;      // 16 waves per CU behind ONE barrier participant
+    if (e.persist_trace) {
+        if (!g_trace && (rc = hip_check(hipMalloc(&g_trace, sizeof(unsigned long long) * 6 * kTraceSteps), "alloc phase trace"))) return rc;
+        if ((rc = hip_check(hipMemsetAsync(g_trace, 0, sizeof(unsigned long long) * 6 * kTraceSteps, stream), "zero phase trace"))) return rc;
+        pa.trace = g_trace;
+    }
+    // 1024 threads: 16 waves per CU behind ONE barrier participant (<= 128 VGPRs); 512: half the waves, twice the registers
     const int D = a.D;
-#define KGE_PERSIST(MODEL, LL, CC) hipLaunchKernelGGL((persistent_steps_kernel<MODEL, LL, CC, THREADS>), dim3(blocks), dim3(THREADS), 0, stream, pa)
+    const bool wide = e.persist_threads != 512;
+#define KGE_PERSIST(MODEL, LL, CC)                                                                                                 \
+    {                                                                                                                              \
+        if (wide) hipLaunchKernelGGL((persistent_steps_kernel<MODEL, LL, CC, 1024>), dim3(blocks), dim3(1024), 0, stream, pa);     \
+        else hipLaunchKernelGGL((persistent_steps_kernel<MODEL, LL, CC, 512>), dim3(blocks), dim3(512), 0, stream, pa);            \
+    }
 #define KGE_PERSIST_D(MODEL)                                                                   \
-    if (D <= 16) KGE_PERSIST(MODEL, 16, 1); else if (D <= 32) KGE_PERSIST(MODEL, 16, 2);       \
-    else if (D <= 64) KGE_PERSIST(MODEL, 16, 4); else if (D <= 128) KGE_PERSIST(MODEL, 32, 4); \
-    else KGE_PERSIST(MODEL, 64, 4);
+    if (D <= 16) KGE_PERSIST(MODEL, 16, 1) else if (D <= 32) KGE_PERSIST(MODEL, 16, 2)         \
+    else if (D <= 64) KGE_PERSIST(MODEL, 16, 4) else if (D <= 128) KGE_PERSIST(MODEL, 32, 4)   \
+    else KGE_PERSIST(MODEL, 64, 4)
     switch (m->model) {
         case KGE_TRANSE: KGE_PERSIST_D(KGE_TRANSE) break;
         case KGE_TRANSH: KGE_PERSIST_D(KGE_TRANSH) break;
@@ -355,6 +378,14 @@ extern "C" int kge_train_steps_persistent(const kge_model_desc *m, float *const 
                        (long long)B, (long long)s.per_thread, (unsigned long long)(1 + 2 * negRate + negRelRate) * (unsigned long long)n_steps);
     e.dev.streams_sync = 2;
     return hip_check(hipGetLastError(), "persistent steps launch");
+}
+
+// test / measurement hook: the phase-boundary stamps of the last traced launch (6 per step, 100 MHz ticks), up to n_steps steps
+extern "C" int kge_persistent_trace(uint64_t *h_out, INT n_steps) {
+    if (!h_out || n_steps < 0) return fail(KGE_ERR_BAD_ARG, "kge_persistent_trace: bad arguments");
+    if (!g_trace) return fail(KGE_ERR_BAD_ARG, "kge_persistent_trace: set option persist_trace and run a launch first");
+    if (n_steps > kTraceSteps) n_steps = kTraceSteps;
+    return hip_check(hipMemcpy(h_out, g_trace, sizeof(uint64_t) * 6 * (size_t)n_steps, hipMemcpyDeviceToHost), "read phase trace");
 }
 
 extern "C" int kge_persistent_aborted(int32_t *flag) {

@@ -63,23 +63,41 @@ def test_persistent_steps_equal_separate_launches(fb_dir, wn_dir, model, graph, 
 
 @pytest.mark.parametrize("model,graph,dim", [("transe", "fb", 100), ("transh", "wn", 200)])
 def test_persistent_steps_match_oracle(fb_dir, wn_dir, model, graph, dim):
-    """configs[0] and configs[2] at their auto batch: S steps in one launch against S oracle steps on the oracle's own
-    batches (same rng streams): losses and tables within 1e-5 / 2e-5, rng states identical afterwards."""
+    """configs[0] and configs[2] at their auto batch through the persistent launch against the oracle.  Each launch (one
+    step, so that the oracle can restart from the engine's tables: two fp32 trajectories of this loss drift apart at every
+    element of e within rounding of zero) must give the oracle's loss and one-step update to 1e-5; rows outside it have to be
+    rows of a group with such an element (tests/torch_ref.py::near_kink_rows).  Multi-step launches are pinned to the
+    one-launch-per-stage path by test_persistent_steps_equal_separate_launches."""
+    from torch_ref import near_kink_rows
     path = fb_dir if graph == "fb" else wn_dir
-    S, alpha, n = 4, 0.01, 1
+    alpha, n = 0.01, 1
     con = engine(path, {"transe": "TransE", "transh": "TransH"}[model], dim, 0, n, alpha)
     kg = oracle.KG(path, work_threads=8, bern=0)
     kg.set_stream_states(con.get_stream_states())
-    start = con.get_parameters()
-    orc = oracle.Model(model, con.entTotal, con.relTotal, dim, dim, margin=1.0, params=start)
     B = con.batch_size
-    want = []
-    for _ in range(S):
+    orc = oracle.Model(model, con.entTotal, con.relTotal, dim, dim, margin=1.0, params=con.get_parameters())
+    outside = kink_elems = 0
+    for launch in range(3):
+        start = con.get_parameters()
+        orc.params = {k: v.copy() for k, v in start.items()}
         bh, bt, br, _ = kg.sampling(B, n, 0)
-        want.append(orc.sgd_step(bh, bt, br, B, n, alpha))
-    got = con.train_steps(S, persistent=True)
-    assert con.get_stream_states().tolist() == kg.stream_states().tolist()
-    assert np.allclose(got, want, rtol=1e-5, atol=0), (got, want)
-    err = update_err(con.get_parameters(), orc.params, start)
-    parity_report("persistent_vs_oracle[%s]" % model, steps=S, batch=B, update_relerr=err)
-    assert err <= 5e-5, err
+        want = orc.sgd_step(bh, bt, br, B, n, alpha)
+        got = con.train_steps(1, persistent=True)
+        assert con.get_stream_states().tolist() == kg.stream_states().tolist()
+        assert abs(got[0] - want) <= 1e-5 * abs(want), (got, want)
+        after = con.get_parameters()
+        kink = None
+        for k in orc.params:
+            du_o = orc.params[k].astype(np.float64) - start[k]
+            du_g = after[k].astype(np.float64) - start[k]
+            quantum = np.abs(start[k]).max() * 2.0 ** -23
+            bad = np.nonzero((np.abs(du_g - du_o) > 1e-5 * np.abs(du_o).max() + quantum).reshape(du_o.shape[0], -1).any(1))[0]
+            if len(bad):
+                if kink is None:
+                    kink, n_el = near_kink_rows(model, start, bh, bt, br, B, n, dim, dim, tol=3e-7)
+                    kink_elems += n_el
+                outside += len(bad)
+                assert not set(bad.tolist()) - kink[k], (k, sorted(set(bad.tolist()) - kink[k])[:10])
+    parity_report("persistent_vs_oracle[%s]" % model, launches=3, batch=B, update_rows_outside_1e5=outside,
+                  elements_of_e_within_3e7_of_zero=kink_elems)
+    assert outside <= 6 * kink_elems
