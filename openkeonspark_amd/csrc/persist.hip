@@ -120,6 +120,7 @@ struct PersistArgs {
 };
 
 constexpr int kTraceSteps = 256;
+constexpr int kTraceBlocks = 1024;    // per-workgroup phase-B durations of step 16 follow the per-step stamps
 __device__ __forceinline__ void stamp(const PersistArgs &pa, int step, int slot) {
     if (pa.trace && blockIdx.x == 0 && threadIdx.x == 0 && step < kTraceSteps) pa.trace[step * 6 + slot] = wall_clock64();
 }
@@ -164,10 +165,33 @@ __global__ __launch_bounds__(THREADS) void persistent_steps_kernel(PersistArgs p
     tm.D = pa.fb.D;
     const int team_in_block = threadIdx.x / L;
     const long long tid = (long long)blockIdx.x * THREADS + threadIdx.x, stride = (long long)gridDim.x * THREADS;
-    const int kshift = pa.sm.kshift, kp = 1 + pa.sm.neg + pa.sm.negrel;
-    const unsigned long long draws = 1ull + 2ull * pa.sm.neg + pa.sm.negrel;
+    const long long batch_len = pa.B * (1 + pa.sm.neg + pa.sm.negrel);
+    // Groups are dealt round-robin over the workgroups (group b -> workgroup b % grid, team slot b / grid): at the reference's
+    // batch sizes a workgroup then has fewer groups than teams, and its idle teams draw the NEXT step's batch meanwhile (the
+    // sampler never reads the parameters): sampling leaves the critical path.  Batches alternate between two buffers.
+    const long long G = (pa.B + gridDim.x - 1) / gridDim.x;          // most groups any workgroup holds
+    const bool ahead = G < TEAMS;
+    const long long s_threads = ahead ? (long long)(TEAMS - G) * L : THREADS;
+    const long long s_first = ahead ? G * L : 0;
+    auto sample_batch = [&](int step, long long stid, long long sstride) {
+        const int kshift = pa.sm.kshift, kp = 1 + pa.sm.neg + pa.sm.negrel;
+        const unsigned long long draws = 1ull + 2ull * pa.sm.neg + pa.sm.negrel;
+        int32_t *oh_p = pa.sm.out_h + (long long)(step & 1) * 3 * batch_len;
+        for (long long g = stid; (g >> kshift) < pa.B; g += sstride) {
+            const long long b = g >> kshift, k = g & ((1 << kshift) - 1);
+            if (k >= kp) continue;
+            // virtual thread id's slice holds min(per_thread, B - id*per_thread) positions per batch: that many * draws per step
+            const long long id = (long long)((unsigned)b / (unsigned)pa.sm.per_thread);
+            long long len = pa.B - id * pa.sm.per_thread;
+            len = len < 0 ? 0 : (len > pa.sm.per_thread ? pa.sm.per_thread : len);
+            int oh, ot, orr;
+            sample_slot(pa.sm, b, k, (unsigned long long)step * (unsigned long long)len * draws, oh, ot, orr);
+            const long long o = b + k * pa.sm.out_stride;
+            oh_p[o] = oh; oh_p[batch_len + o] = ot; oh_p[2 * batch_len + o] = orr;
+        }
+    };
     for (int step = 0; step <= pa.n_steps; step++) {
-        // ---------------- phase A: update of step-1, loss of step-1, sampling of this step ----------------
+        // ---------------- phase A: update and loss of step-1 (and, when no team is idle in phase B, sampling of this step) ----------------
         stamp(pa, step, 0);
         if (step > 0) {
             const float lr = pa.lr[step - 1];
@@ -187,25 +211,23 @@ __global__ __launch_bounds__(THREADS) void persistent_steps_kernel(PersistArgs p
         }
         if (step == pa.n_steps) break;
         stamp(pa, step, 1);
-        for (long long g = tid; (g >> kshift) < pa.B; g += stride) {
-            const long long b = g >> kshift, k = g & ((1 << kshift) - 1);
-            if (k >= kp) continue;
-            // thread id's slice holds min(per_thread, B - id*per_thread) positions per batch: that many * draws per step
-            const long long id = (long long)((unsigned)b / (unsigned)pa.sm.per_thread);
-            long long len = pa.B - id * pa.sm.per_thread;
-            len = len < 0 ? 0 : (len > pa.sm.per_thread ? pa.sm.per_thread : len);
-            int oh, ot, orr;
-            sample_slot(pa.sm, b, k, (unsigned long long)step * (unsigned long long)len * draws, oh, ot, orr);
-            const long long o = b + k * pa.sm.out_stride;
-            pa.sm.out_h[o] = oh; pa.sm.out_t[o] = ot; pa.sm.out_r[o] = orr;
-        }
+        if (!ahead || step == 0) sample_batch(step, tid, stride);
         stamp(pa, step, 2);
         if (!grid_barrier(pa.bar, bs, &ok_lds)) return;
         stamp(pa, step, 3);
-        // ---------------- phase B: forward / hinge / backward of this step's batch ----------------
+        // ---------------- phase B: forward / hinge / backward of this step's batch; idle teams sample the next one ----------------
+        const unsigned long long tb0 = (pa.trace && step == 16 && threadIdx.x == 0) ? wall_clock64() : 0ull;
+        FbArgs fb = pa.fb;
+        fb.bh = pa.fb.bh + (long long)(step & 1) * 3 * batch_len;
+        fb.bt = fb.bh + batch_len;
+        fb.br = fb.bh + 2 * batch_len;
         float lsum = 0.f;
-        for (long long b = (long long)blockIdx.x * TEAMS + team_in_block; b < pa.B; b += (long long)gridDim.x * TEAMS)
-            fwdbwd_group<MODEL, L, C, false>(tm, pa.fb, b, lsum);
+        for (long long slot = team_in_block; slot < G; slot += TEAMS) {
+            const long long b = slot * gridDim.x + blockIdx.x;
+            if (b < pa.B) fwdbwd_group<MODEL, L, C, false>(tm, fb, b, lsum);
+        }
+        if (ahead && step + 1 < pa.n_steps && (long long)threadIdx.x >= s_first)
+            sample_batch(step + 1, (long long)blockIdx.x * s_threads + (threadIdx.x - s_first), (long long)gridDim.x * s_threads);
         if (tm.lane == 0) red[team_in_block] = lsum;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -213,6 +235,10 @@ __global__ __launch_bounds__(THREADS) void persistent_steps_kernel(PersistArgs p
 #pragma unroll
             for (int i = 0; i < TEAMS; i++) s += red[i];
             pa.partials[(long long)(step & 1) * gridDim.x + blockIdx.x] = s;
+        }
+        if (pa.trace && step == 16 && threadIdx.x == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pa.trace[6 * kTraceSteps + blockIdx.x] = wall_clock64() - tb0;
         }
         stamp(pa, step, 4);
         if (!grid_barrier(pa.bar, bs, &ok_lds)) return;
@@ -279,7 +305,7 @@ extern "C" int kge_train_steps_persistent(const kge_model_desc *m, float *const 
     if (batch_len > g_batch_cap) {
         if (g_batch) (void)hipFree(g_batch);
         g_batch = nullptr;
-        if ((rc = hip_check(hipMalloc(&g_batch, sizeof(int32_t) * 3 * (size_t)batch_len), "alloc persistent batch"))) return rc;
+        if ((rc = hip_check(hipMalloc(&g_batch, sizeof(int32_t) * 2 * 3 * (size_t)batch_len), "alloc persistent batch"))) return rc;   // two batches: this step's and the next
         g_batch_cap = batch_len;
     }
     if (n_steps > g_lr_cap) {
@@ -349,8 +375,8 @@ extern "C" int kge_train_steps_persistent(const kge_model_desc *m, float *const 
     pa.lr = g_lr; pa.losses = d_losses; pa.partials = g_partials; pa.bar = g_bar;
     pa.B = B; pa.W = (int)W;
     if (e.persist_trace) {
-        if (!g_trace && (rc = hip_check(hipMalloc(&g_trace, sizeof(unsigned long long) * 6 * kTraceSteps), "alloc phase trace"))) return rc;
-        if ((rc = hip_check(hipMemsetAsync(g_trace, 0, sizeof(unsigned long long) * 6 * kTraceSteps, stream), "zero phase trace"))) return rc;
+        if (!g_trace && (rc = hip_check(hipMalloc(&g_trace, sizeof(unsigned long long) * (6 * kTraceSteps + kTraceBlocks)), "alloc phase trace"))) return rc;
+        if ((rc = hip_check(hipMemsetAsync(g_trace, 0, sizeof(unsigned long long) * (6 * kTraceSteps + kTraceBlocks), stream), "zero phase trace"))) return rc;
         pa.trace = g_trace;
     }
     // 1024 threads: 16 waves per CU behind ONE barrier participant (<= 128 VGPRs); 512: half the waves, twice the registers
@@ -384,7 +410,7 @@ extern "C" int kge_train_steps_persistent(const kge_model_desc *m, float *const 
 extern "C" int kge_persistent_trace(uint64_t *h_out, INT n_steps) {
     if (!h_out || n_steps < 0) return fail(KGE_ERR_BAD_ARG, "kge_persistent_trace: bad arguments");
     if (!g_trace) return fail(KGE_ERR_BAD_ARG, "kge_persistent_trace: set option persist_trace and run a launch first");
-    if (n_steps > kTraceSteps) n_steps = kTraceSteps;
+    if (n_steps > kTraceSteps + kTraceBlocks / 6) n_steps = kTraceSteps + kTraceBlocks / 6;   // (rows beyond 256: per-workgroup phase-B ticks of step 16)
     return hip_check(hipMemcpy(h_out, g_trace, sizeof(uint64_t) * 6 * (size_t)n_steps, hipMemcpyDeviceToHost), "read phase trace");
 }
 

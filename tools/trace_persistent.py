@@ -24,15 +24,18 @@ def run(name, spec, model, dim, n, threads, steps=200):
     con.train_steps(steps, persistent=True)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     L.kge_set_option(b"persist_trace", 0)
-    tr = np.zeros((steps, 6), np.uint64)
-    pkg._lib.check(L.kge_persistent_trace(tr.ctypes.data, steps), L)
-    tr = tr.astype(np.int64)
+    raw = np.zeros((256 + 64, 6), np.uint64)
+    pkg._lib.check(L.kge_persistent_trace(raw.ctypes.data, 256 + 64), L)
+    tr = raw[:steps].astype(np.int64)
+    per_block = raw[256:].reshape(-1)[:256].astype(np.int64) / 100.0
     us = lambda a: float(np.median(a)) / 100.0
     body = tr[2:steps - 1]
     nxt = tr[3:steps, 0]
     out = {"config": name, "threads": threads, "batch": con.batch_size, "us_per_step_wall": dt / steps * 1e6,
            "sweep": us(body[:, 1] - body[:, 0]), "sampling": us(body[:, 2] - body[:, 1]), "barrier1": us(body[:, 3] - body[:, 2]),
-           "fwdbwd": us(body[:, 4] - body[:, 3]), "barrier2": us(body[:, 5] - body[:, 4]), "step_by_stamps": us(nxt - body[:, 0])}
+           "fwdbwd": us(body[:, 4] - body[:, 3]), "barrier2": us(body[:, 5] - body[:, 4]), "step_by_stamps": us(nxt - body[:, 0]),
+           "fwdbwd_per_block_us": {"min": float(per_block.min()), "p50": float(np.median(per_block)), "p90": float(np.percentile(per_block, 90)),
+                                   "max": float(per_block.max())}}
     print(json.dumps(out), flush=True)
 
 
