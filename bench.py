@@ -10,7 +10,8 @@ negatives per positive with Bernoulli head/tail skew, margin 1.0.  Arithmetic an
 One "step" = what the reference does per loop iteration (distribute_training.py:274-282):
 sample a batch (on the device), forward, backward, optimiser update -- all inside the timed region,
 inputs resident in HBM.  N GPUs = N processes, rank g owns the virtual sampler threads
-[g*8/N, (g+1)*8/N); gradients are all-reduced over RCCL.  Per-GPU batch is held at ~34 014 positives
+[g*8/N, (g+1)*8/N); the integer count image is reduce-scattered over RCCL, every rank applies Adam to its
+chunk of the tables and the updated chunks are all-gathered.  Per-GPU batch is held at ~34 014 positives
 (nbatches = 8/N), so scaling is weak.
 
 python bench.py --gpus N --steps K --warmup W      (torchrun-launched for N > 1)
@@ -58,30 +59,41 @@ def usable_cpus(omp_max):
     return max(1, min(n, int(os.environ.get("KGE_CPU_BASELINE_THREADS", "64"))))
 
 
-def cpu_baseline(fb_dir, seconds=12.0):
-    """The CPU oracle (C restatement of the reference path: sampler + TransE fwd/bwd + TF1 Adam) timed
-    on this host, all cores for the model part, on a bounded sample of the same workload."""
-    import numpy as np
+def cpu_baseline(fb_dir, B, seconds=15.0):
+    """The CPU oracle (C restatement of the reference path: sampler + TransE fwd/bwd + TF1 Adam) timed on this host on
+    a bounded sample of the SAME workload (same graph, same per-step batch).  The fast CPU form: forward/backward over all
+    granted cores with thread-private gradient accumulators (no atomic adds), the sampler with one OS thread per virtual
+    thread as the reference's pthreads run it (Base.cpp:151-171) or serially, whichever is quicker here."""
     from oracle import oracle
     threads = usable_cpus(oracle.lib().orc_max_threads())
     kg = oracle.KG(fb_dir, work_threads=WORK_THREADS, bern=1)
-    B = 4096
     m = oracle.Model("transe", kg.entTotal, kg.relTotal, DIM, margin=1.0, seed=0)
-    # warm-up
-    bh, bt, br, _ = kg.sampling(B, NEG, 0)
-    m.adam_step(bh, bt, br, B, NEG, 0.001, nthreads=threads)
+    timings = {}
+    for par in (False, True):     # warm-up doubles as the sampler choice
+        t0 = time.perf_counter()
+        bh, bt, br, _ = kg.sampling(B, NEG, 0, parallel=par)
+        timings[par] = time.perf_counter() - t0
+    par = timings[True] < timings[False]
+    m.adam_step(bh, bt, br, B, NEG, 0.001, nthreads=-threads if threads > 1 else 1)
     t0 = time.perf_counter()
     steps = 0
     while True:
-        bh, bt, br, _ = kg.sampling(B, NEG, 0)
-        m.adam_step(bh, bt, br, B, NEG, 0.001, nthreads=threads)
+        bh, bt, br, _ = kg.sampling(B, NEG, 0, parallel=par)
+        m.adam_step(bh, bt, br, B, NEG, 0.001, nthreads=-threads if threads > 1 else 1)
         steps += 1
         if time.perf_counter() - t0 >= seconds or steps >= 200:
             break
     dt = time.perf_counter() - t0
     return {"value": B * steps / dt, "unit": "positive triples/s", "cores": int(threads), "kind": "port",
-            "sample": "%d steps of B=%d positives x %d negatives, TransE dim=%d, TF1 Adam; oracle/kge_oracle.c "
-                      "(sampler 1 thread + OpenMP forward/backward)" % (steps, B, NEG, DIM)}
+            "sample": "%d steps of B=%d positives x %d negatives (the GPU's per-step batch), TransE dim=%d, TF1 Adam; "
+                      "oracle/kge_oracle.c: OpenMP forward/backward with thread-private accumulators, sampler %s"
+                      % (steps, B, NEG, DIM, "one thread per virtual thread" if par else "single thread")}
+
+
+def adam_step_bytes(ent_total, rel_total, dim):
+    """TF1 'sparse' Adam is a dense sweep: every element of p, m, v is read and written each step
+    (24 B) and the summed gradient image is read and re-zeroed (8 B)."""
+    return (ent_total + rel_total) * dim * 32
 
 
 def main():
@@ -106,7 +118,7 @@ def main():
     if os.environ.get("KGE_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0   # rehearsal of the N-rank code path on a one-GPU box (with KGE_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
-    # KGE_BENCH_FORCE_DIST=1 exercises the RCCL code path (process group, int32 all-reduce) with a single rank
+    # KGE_BENCH_FORCE_DIST=1 initialises the RCCL process group even with a single rank
     use_dist = world > 1 or os.environ.get("KGE_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -152,7 +164,6 @@ def main():
     con.set_model_and_session(TransE)
     if use_dist:
         con.init_distributed()
-        con.world_size = max(con.world_size, 2) if world == 1 else con.world_size  # force the all-reduce even with one rank
     sys.stdout.flush()
     con.lib.kge_clear_error()
     import ctypes
@@ -169,6 +180,7 @@ def main():
         torch.cuda.synchronize()
 
     import ctypes
+    from openkeonspark_amd import _lib as _l
     for _ in range(args.warmup):
         con.train_step(sync=False)
     sync()
@@ -180,27 +192,40 @@ def main():
         con.train_step(sync=False)
     sync()
     dt = time.perf_counter() - t0
-    con.lib.kge_set_option(b"time_emit", 0)
     if use_dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(con._loss.item())
+    # the kernel-duration sample must not depend on how few steps the caller timed: keep stepping (outside the timed
+    # region, same training run) until at least 50 launches carry an event pair
     ms = ctypes.c_float()
     timed = ctypes.c_int64()
-    from openkeonspark_amd import _lib as _l
+    in_region = (args.steps + 3) // 4
+    extra = 0
+    while in_region + extra // 4 < 50 and extra < 400:
+        con.train_step(sync=False)
+        extra += 1
+    sync()
+    con.lib.kge_set_option(b"time_emit", 0)
     _l.check(con.lib.kge_kernel_ms_mean(b"transe_emit", ctypes.byref(ms), ctypes.byref(timed)), con.lib)
     kern_ms = float(ms.value)
     n_pos = n_local
     alg_bytes = algorithmic_bytes_per_positive(NEG, DIM) * n_pos
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_note = None, None
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr_path):
         try:
-            traffic = json.load(open(tr_path)).get("emit_hbm_bytes_per_launch")
+            tr = json.load(open(tr_path))
+            traffic = tr.get("emit_hbm_bytes_per_launch")
+            traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at commit %s (%s)" % (
+                tr.get("measured_at_commit", "?"), tr.get("source", "profiles/"))
         except Exception:
             traffic = None
+    # whole-step figure: the gather the emit kernel does + TF1 Adam's dense sweep, over the step time (all kernels)
+    step_bytes = alg_bytes + adam_step_bytes(con.entTotal, con.relTotal, DIM)
+    step_gbps = step_bytes / (dt / args.steps) / 1e9
 
     if rank == 0:
         out = {
@@ -219,11 +244,14 @@ def main():
                        "parallelism": "dp%d" % world, "final_loss": loss},
             "roofline": {"bound": "hbm", "kernel": "kge::transe_emit_vec_kernel<64,1,4,1,true>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms": kern_ms, "kernel_launches_timed": int(timed.value),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "traffic": traffic, "traffic_source": traffic_note, "kernel_ms": kern_ms,
+                         "kernel_launches_timed": int(timed.value), "kernel_launches_timed_inside_region": in_region,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "step": {"algorithmic_bytes": step_bytes, "achieved": step_gbps, "frac": step_gbps / HBM_PEAK_GBS,
+                                  "unit": "GB/s", "what": "gather bytes of the step + the dense TF1 Adam sweep, over ms_per_step"}},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(fb_dir)
+            out["cpu_baseline"] = cpu_baseline(fb_dir, n_local)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

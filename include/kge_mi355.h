@@ -123,6 +123,8 @@ const char *kge_version(void);
  *   "transr_v1":         1 = TransR always on the 32x32x2 MFMA tiles, 2 = 16x16x4 tiles with the all-output-tiles
  *                        wgrad forced (test hooks; default 0 = automatic)
  *   "time_emit":         N > 0 = bracket every N-th launch of the TransE emit kernel with HIP events on its launch stream
+ *   "fb_occ4":           1 (default) = TransH / TransD / TransR's vector stage at <= 4 elements per lane run the forward/backward body
+ *                        compiled for four waves per SIMD (128 VGPRs); 0 = the uncapped build
  *   "persist_trace":     1 = kge_train_steps_persistent stamps its phase boundaries (read with kge_persistent_trace)
  *   "persist_threads":   threads per workgroup of the persistent launch, 1024 (default) or 512
  *   "libc_rand_restart": restart the glibc-compatible seed generator, as in a fresh process (the next

@@ -225,6 +225,7 @@ int kge_set_option(const char *name, INT value) {
     if (n == "lp_v1") { engine().lp_v1 = value != 0; return KGE_OK; }
     if (n == "transr_v1") { engine().transr_v1 = (int)value; return KGE_OK; }
     if (n == "time_emit") { engine().time_emit = value > 0 ? (int)value : 0; if (value > 0) { engine().emit_launches = 0; engine().emit_seen = 0; } return KGE_OK; }
+    if (n == "fb_occ4") { engine().fb_occ4 = value != 0; return KGE_OK; }
     if (n == "persist_trace") { engine().persist_trace = value != 0; return KGE_OK; }
     if (n == "persist_threads") { engine().persist_threads = value == 512 ? 512 : 1024; return KGE_OK; }
     if (n == "libc_rand_restart") { engine().libc = LibcRand(); return KGE_OK; }  // as in a fresh process

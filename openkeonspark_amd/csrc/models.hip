@@ -70,13 +70,6 @@ __device__ __forceinline__ void store_record(const FbArgs &a, int lane, long lon
     for (int q = 0; q < Q; q++) p[lane + L * q] = w[q];
 }
 
-// team-uniform broadcast of lane `src` (index inside the team)
-template <int L>
-__device__ __forceinline__ int team_bcast(int v, int src) {
-    if constexpr (L == 64) return __builtin_amdgcn_readlane(v, src);  // wave == team: uniform result in an SGPR
-    else return __shfl(v, src, L);
-}
-
 template <int L, int C>
 __global__ __launch_bounds__(256) void transe_emit_kernel(FbArgs a) {
     constexpr int TEAMS = 256 / L;
@@ -620,10 +613,10 @@ static void launch_fb(const FbArgs &a, float *d_loss, hipStream_t stream) {
     if (blocks < 1) blocks = 1;
     FbArgs f = a;
     f.loss_out = d_loss; f.loss_ticket = engine().dev.loss_ticket;   // the last block writes the loss
-    if constexpr (MODEL != KGE_TRANSE && C <= 4)
-        hipLaunchKernelGGL((fwdbwd_kernel_occ4<MODEL, L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
-    else
-        hipLaunchKernelGGL((fwdbwd_kernel<MODEL, L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
+    if constexpr (MODEL != KGE_TRANSE && C <= 4) {
+        if (engine().fb_occ4) { hipLaunchKernelGGL((fwdbwd_kernel_occ4<MODEL, L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, f); return; }
+    }
+    hipLaunchKernelGGL((fwdbwd_kernel<MODEL, L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
 }
 
 template <int MODEL, int L, int C>
@@ -634,10 +627,10 @@ static void launch_fb_records(const FbArgs &a, float *d_loss, hipStream_t stream
     if (blocks < 1) blocks = 1;
     FbArgs f = a;
     f.loss_out = d_loss; f.loss_ticket = engine().dev.loss_ticket;
-    if constexpr ((MODEL == KGE_TRANSH || MODEL == KGE_TRANSD) && C <= 4)
-        hipLaunchKernelGGL((fwdbwd_kernel_occ4<MODEL, L, C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
-    else
-        hipLaunchKernelGGL((fwdbwd_kernel<MODEL, L, C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
+    if constexpr ((MODEL == KGE_TRANSH || MODEL == KGE_TRANSD) && C <= 4) {
+        if (engine().fb_occ4) { hipLaunchKernelGGL((fwdbwd_kernel_occ4<MODEL, L, C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, f); return; }
+    }
+    hipLaunchKernelGGL((fwdbwd_kernel<MODEL, L, C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
 }
 
 template <int MODEL>

@@ -124,12 +124,9 @@ struct Side {
     bool uc;
 };
 
-// Projection onto the relation context.  TransH.py:12-14: e - (e.w^)w^ ; TransD.py:23-25: e + (e.e_p) r_p
+// Projection onto the relation context (rows already in s.raw / s.aux).  TransH.py:12-14: e - (e.w^)w^ ; TransD.py:23-25: e + (e.e_p) r_p
 template <int MODEL, int L, int C>
-__device__ __forceinline__ void side_forward(const Team<L, C> &tm, const FbArgs &a, long long row, const float (&cw)[C],
-                                             Side<C> &s) {
-    if constexpr (MODEL == KGE_TRANSR) tm.load(a.P, row, s.raw);  // row = slot of the projected buffer
-    else tm.load(a.ent, row, s.raw);
+__device__ __forceinline__ void side_project(const Team<L, C> &tm, const float (&cw)[C], Side<C> &s) {
     float xp[C];
     if constexpr (MODEL == KGE_TRANSE || MODEL == KGE_TRANSR) {
 #pragma unroll
@@ -140,12 +137,20 @@ __device__ __forceinline__ void side_forward(const Team<L, C> &tm, const FbArgs 
 #pragma unroll
         for (int c = 0; c < C; c++) xp[c] = s.raw[c] - s.a * cw[c];
     } else {
-        tm.load(a.auxe, row, s.aux);
         s.a = tm.dot(s.raw, s.aux);
 #pragma unroll
         for (int c = 0; c < C; c++) xp[c] = s.raw[c] + s.a * cw[c];
     }
     tm.normalize(xp, s.nrm, s.inv, s.uc);
+}
+
+template <int MODEL, int L, int C>
+__device__ __forceinline__ void side_forward(const Team<L, C> &tm, const FbArgs &a, long long row, const float (&cw)[C],
+                                             Side<C> &s) {
+    if constexpr (MODEL == KGE_TRANSR) tm.load(a.P, row, s.raw);  // row = slot of the projected buffer
+    else tm.load(a.ent, row, s.raw);
+    if constexpr (MODEL == KGE_TRANSD) tm.load(a.auxe, row, s.aux);
+    side_project<MODEL, L, C>(tm, cw, s);
 }
 
 // Backward of one entity side given G = dL/d(normalised projected vector).  Adds the row gradient(s)
@@ -287,6 +292,13 @@ __device__ __forceinline__ bool standalone_negative(const Team<L, C> &tm, const 
     }
     ctx_backward<MODEL, L, C>(tm, a, nr, cx, G, acw);
     return true;
+}
+
+// team-uniform broadcast of lane `src` (index inside the team)
+template <int L>
+__device__ __forceinline__ int team_bcast(int v, int src) {
+    if constexpr (L == 64) return __builtin_amdgcn_readlane(v, src);  // wave == team: uniform result in an SGPR
+    else return __shfl(v, src, L);
 }
 
 // One positive and all its negatives: forward, hinge, backward, gradient rows out (atomic adds or float records).

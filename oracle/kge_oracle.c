@@ -287,8 +287,9 @@ static i64 corrupt(OrcKG *kg, i64 id, CorruptKind kind, i64 anchor, i64 key) {
 /* Base.cpp:74-143 (getBatch) for one virtual thread, Base.cpp:149-172 (sampling) for all of them.
  * Threads write disjoint slices from independent streams, so running them one after another gives
  * the reference's output whatever the pthread schedule was. */
-void orc_sampling(OrcKG *kg, i64 *bh, i64 *bt, i64 *br, float *by, i64 B, i64 neg, i64 negrel) {
+static void sampling_impl(OrcKG *kg, i64 *bh, i64 *bt, i64 *br, float *by, i64 B, i64 neg, i64 negrel, int parallel) {
     i64 W = kg->work_threads;
+#pragma omp parallel for schedule(static, 1) if (parallel)
     for (i64 id = 0; id < W; id++) {
         i64 lef, rig;
         if (B % W == 0) { lef = id * (B / W); rig = (id + 1) * (B / W); }           /* Base.cpp:85-87 */
@@ -317,6 +318,14 @@ void orc_sampling(OrcKG *kg, i64 *bh, i64 *bt, i64 *br, float *by, i64 B, i64 ne
             }
         }
     }
+}
+
+void orc_sampling(OrcKG *kg, i64 *bh, i64 *bt, i64 *br, float *by, i64 B, i64 neg, i64 negrel) {
+    sampling_impl(kg, bh, bt, br, by, B, neg, negrel, 0);
+}
+/* the same with one OS thread per virtual thread, as the reference's pthreads run it (Base.cpp:151-171): same output */
+void orc_sampling_parallel(OrcKG *kg, i64 *bh, i64 *bt, i64 *br, float *by, i64 B, i64 neg, i64 negrel) {
+    sampling_impl(kg, bh, bt, br, by, B, neg, negrel, 1);
 }
 
 /* ==========================================================================================
@@ -552,17 +561,44 @@ float orc_loss(const OrcModel *M, const i64 *bh, const i64 *bt, const i64 *br, i
 float orc_grad(const OrcModel *M, const i64 *bh, const i64 *bt, const i64 *br, i64 B, i64 N,
                i64 denom, float *grads[4], int nthreads) {
     float *ps = malloc(sizeof(float) * (size_t)B), *ns = malloc(sizeof(float) * (size_t)(B * N));
+    /* nthreads < 0: |nthreads| threads with THREAD-PRIVATE accumulators summed at the end (no atomic adds): the fast CPU
+     * form, used as bench.py's cpu_baseline */
+    const int private_acc = nthreads < -1;
+    if (private_acc) nthreads = -nthreads;
     if (nthreads < 1) nthreads = 1;
     float loss = forward_all(M, bh, bt, br, B, N, ps, ns, nthreads);
     if (denom != B * N) loss = loss * (float)(B * N) / (float)denom;
     float unit = 1.0f / (float)denom;
     i64 rows[4]; int width[4];
     table_shapes(M, rows, width);
+    static float *priv[64][4];      /* cached per-thread accumulators of the private form */
+    static size_t priv_elems[4];
+    if (private_acc) {
+        if (nthreads > 64) nthreads = 64;
+        for (int i = 0; i < 4; i++) {
+            size_t n = grads[i] ? (size_t)rows[i] * (size_t)width[i] : 0;
+            if (n != priv_elems[i]) {
+                for (int t = 0; t < 64; t++) { free(priv[t][i]); priv[t][i] = NULL; }
+                priv_elems[i] = n;
+            }
+        }
+    }
 #pragma omp parallel num_threads(nthreads)
     {
         Sink K; memset(&K, 0, sizeof K);
-        for (int i = 0; i < 4; i++) { K.g[i] = grads[i]; K.width[i] = width[i]; }
-        K.atomic = nthreads > 1;
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        for (int i = 0; i < 4; i++) {
+            K.g[i] = grads[i]; K.width[i] = width[i];
+            if (private_acc && grads[i]) {
+                if (!priv[tid][i]) priv[tid][i] = malloc(sizeof(float) * priv_elems[i]);
+                memset(priv[tid][i], 0, sizeof(float) * priv_elems[i]);
+                K.g[i] = priv[tid][i];
+            }
+        }
+        K.atomic = nthreads > 1 && !private_acc;
         Scratch *S = malloc(sizeof(Scratch));
 #pragma omp for schedule(static)
         for (i64 b = 0; b < B; b++) {
@@ -583,6 +619,18 @@ float orc_grad(const OrcModel *M, const i64 *bh, const i64 *bt, const i64 *br, i
             }
         }
         free(S);
+        if (private_acc) {   /* every thread sums its share of the elements over all the private copies, in thread order */
+#pragma omp barrier
+            for (int i = 0; i < 4; i++) {
+                if (!grads[i]) continue;
+#pragma omp for schedule(static)
+                for (i64 e = 0; e < (i64)priv_elems[i]; e++) {
+                    float acc = grads[i][e];
+                    for (int t = 0; t < nthreads; t++) acc += priv[t][i][e];
+                    grads[i][e] = acc;
+                }
+            }
+        }
     }
     free(ps); free(ns);
     return loss;

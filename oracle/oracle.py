@@ -57,6 +57,7 @@ def lib():
         L.orc_stream_state.argtypes = [vp, i64]
         L.orc_set_stream_state.argtypes = [vp, i64, ctypes.c_uint64]
         L.orc_sampling.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64]
+        L.orc_sampling_parallel.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64]
         L.orc_loss.restype = f32
         L.orc_loss.argtypes = [vp, vp, vp, vp, i64, i64]
         L.orc_scores.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp]
@@ -151,13 +152,14 @@ class KG:
         for i, s in enumerate(states):
             lib().orc_set_stream_state(self._h, i, int(s))
 
-    def sampling(self, B, neg=1, negrel=0):
+    def sampling(self, B, neg=1, negrel=0, parallel=False):
+        """parallel=True: one OS thread per virtual thread, as the reference's pthreads (same output)."""
         n = B * (1 + neg + negrel)
         h = np.zeros(n, np.int64)
         t = np.zeros(n, np.int64)
         r = np.zeros(n, np.int64)
         y = np.zeros(n, np.float32)
-        lib().orc_sampling(self._h, _p(h), _p(t), _p(r), _p(y), B, neg, negrel)
+        (lib().orc_sampling_parallel if parallel else lib().orc_sampling)(self._h, _p(h), _p(t), _p(r), _p(y), B, neg, negrel)
         return h, t, r, y
 
 
