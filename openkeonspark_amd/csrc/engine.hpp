@@ -60,6 +60,10 @@ struct Engine {
     int hub_copies = 1;         // atomic TransH/TransD path: spread the relation-side rows over copies when a row takes >= 128 adds per step
     int lp_v1 = 0;              // test hook: link prediction through the generic predict kernel on materialised candidate batches
     int transr_v1 = 0;          // test hook: 1 = the 32x32x2 / 32-row-tile TransR kernels even where the v2 tiles apply; 2 = v2 with its all-tiles wgrad forced
+    // bf16 gather mode (non-parity): shadows of the two TransE tables, registered by kge_transe_set_bf16_shadow and kept current by
+    // the apply kernel; the emit kernel gathers from them when asked for exactly these master tables
+    uint16_t *shadow_ent = nullptr, *shadow_rel = nullptr;
+    const float *shadow_for_ent = nullptr, *shadow_for_rel = nullptr;
     int fb_occ4 = 1;            // projecting models at <= 4 elements per lane: the forward/backward body compiled for four waves per SIMD
     int persist_trace = 0;      // measurement hook: the persistent launch stamps its phase boundaries (kge_persistent_trace)
     int persist_threads = 1024; // threads per workgroup of the persistent launch (1024 or 512)

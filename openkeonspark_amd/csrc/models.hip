@@ -257,7 +257,7 @@ __device__ __forceinline__ uint32_t bytes_of(s16x2 lo, s16x2 hi) {
     return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
 }
 
-template <int L, int Q, int K, int WPE, bool INV_TAB>
+template <int L, int Q, int K, int WPE, bool INV_TAB, bool BF16 = false>
 __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
     constexpr int TEAMS = 256 / L;
     __shared__ float red[TEAMS];
@@ -268,11 +268,23 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
     bool valid[Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) valid[q] = 4 * (lane + L * q) < D;
+    // BF16 (the non-parity fast mode, Config.gather_dtype = "bf16"): rows are gathered from the bf16 SHADOW of the tables the
+    // optimizer keeps beside its fp32 master copy -- 8 bytes per lane instead of 16, same element -> lane mapping, fp32 arithmetic
     auto load4 = [&](const float *__restrict__ tab, long long row, float4 (&x)[Q]) {
-        const float *p = tab + row * D;
+        if constexpr (BF16) {
+            const uint16_t *p = (tab == a.rel ? a.rel16 : a.ent16) + row * D;
 #pragma unroll
-        for (int q = 0; q < Q; q++)
-            x[q] = valid[q] ? *reinterpret_cast<const float4 *>(p + 4 * (lane + L * q)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < Q; q++) {
+                const uint2 w = valid[q] ? *reinterpret_cast<const uint2 *>(p + 4 * (lane + L * q)) : make_uint2(0u, 0u);
+                x[q] = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u), __uint_as_float(w.y << 16),
+                                   __uint_as_float(w.y & 0xFFFF0000u));
+            }
+        } else {
+            const float *p = tab + row * D;
+#pragma unroll
+            for (int q = 0; q < Q; q++)
+                x[q] = valid[q] ? *reinterpret_cast<const float4 *>(p + 4 * (lane + L * q)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
     float lsum = 0.f;
     for (long long b = (long long)blockIdx.x * TEAMS + team_in_block; b < a.n_pos; b += (long long)gridDim.x * TEAMS) {
@@ -476,6 +488,18 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(const float *__restri
     }
 }
 
+__global__ __launch_bounds__(256) void row_inv_norm_bf16_kernel(const uint16_t *__restrict__ ent, const uint16_t *__restrict__ rel, long long E,
+                                                                long long R, int D, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < E + R; row += (long long)gridDim.x * 4) {
+        const uint16_t *p = row < E ? ent + row * D : rel + (row - E) * D;
+        float s = 0.f;
+        for (int e = lane; e < D; e += 64) { const float v = __uint_as_float((uint32_t)p[e] << 16); s += v * v; }
+        s = team_sum<64>(s);
+        if (lane == 0) out[row] = 1.0f / sqrtf(s >= 1e-12f ? s : 1e-12f);
+    }
+}
+
 constexpr int kDeferBlocks = 128;
 
 template <int L, int C>
@@ -491,11 +515,14 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
         // the per-row inverse-norm table costs one sweep of both tables per step: only while they are
         // cache-sized (FB15k-237 x 200: 11.8 MB); beyond 256 MB the norms are computed from the gathered rows
         const bool inv_tab = a.inv_norm != nullptr;
+        const bool bf16 = a.ent16 != nullptr;
         if (inv_tab) {
             long long nb = (a.ent_total + a.rel_total + 3) / 4;
             if (nb > 2048) nb = 2048;
-            hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.ent, a.rel, (long long)a.ent_total,
-                               (long long)a.rel_total, a.D, const_cast<float *>(a.inv_norm));
+            if (bf16) hipLaunchKernelGGL(row_inv_norm_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.ent16, a.rel16,
+                                         (long long)a.ent_total, (long long)a.rel_total, a.D, const_cast<float *>(a.inv_norm));
+            else hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.ent, a.rel, (long long)a.ent_total,
+                                    (long long)a.rel_total, a.D, const_cast<float *>(a.inv_norm));
         }
         Engine &eng = engine();
         const int slot = (int)(eng.emit_launches % Engine::kEmitRing);
@@ -504,7 +531,8 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
             if (!eng.ev_emit0[slot]) { (void)hipEventCreate(&eng.ev_emit0[slot]); (void)hipEventCreate(&eng.ev_emit1[slot]); }
             (void)hipEventRecord(eng.ev_emit0[slot], stream);
         }
-        if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        if (bf16 && inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        else if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         if (timed) { (void)hipEventRecord(eng.ev_emit1[slot], stream); eng.emit_launches++; }
     } else
@@ -584,6 +612,9 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
     }
     FbArgs a = {};
     a.inv_norm = use_inv_table ? inv_norm : nullptr;
+    if (e.shadow_ent && e.shadow_for_ent == ent && e.shadow_for_rel == rel && use_inv_table && m.ent_dim % 4 == 0 && !track_deferred) {
+        a.ent16 = e.shadow_ent; a.rel16 = e.shadow_rel;     // bf16 gather mode: these tables have a registered, current shadow
+    }
     a.group_list = track_deferred ? defer_list : nullptr; a.group_count = defer_count;
     a.ent = ent; a.rel = rel; a.g_ent = resid_ent; a.g_rel = resid_rel;
     a.bh = d_h; a.bt = d_t; a.br = d_r;
