@@ -40,6 +40,8 @@ struct TrWork {
     int32_t *keys = nullptr, *keys2 = nullptr, *vals = nullptr, *vals2 = nullptr, *job_ent = nullptr;
     int32_t *bucket_start = nullptr;  // [R+2]
     int32_t *tile_rel = nullptr, *tile_row0 = nullptr, *n_tiles = nullptr;
+    int32_t *rel_hist = nullptr;      // two alternating pairs of [kRelBins] bucket sizes + [kRelBins] scatter cursors
+    int rel_parity = 0;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     int64_t cap_slots = 0, cap_dim = 0, cap_rel = 0, cap_tiles = 0;
@@ -141,6 +143,99 @@ __global__ __launch_bounds__(1024) void bounds_kernel(const int32_t *__restrict_
     int t = chunk_tiles[threadIdx.x];
     for (int r = r0; r < r1; r++)
         for (int row = bucket_start[r]; row < bucket_start[r + 1]; row += tile_rows) { tile_rel[t] = r; tile_row0[t] = row; t++; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Counting sort of the jobs by matrix relation (R + 1 keys: the last one collects the alias slots) in two launches, with the
+// bucket starts and the (relation, row tile) map as by-products -- instead of rocPRIM's radix sort (4-8 launches) plus the
+// single-workgroup bounds kernel: at the reference's batch sizes those launches were a sixth of the TransR step.
+// The order inside a bucket is whatever the cursors hand out (projection and dgrad are per-row; wgrad sums a bucket's rows
+// in a different order from run to run, as its atomics already did).
+// ---------------------------------------------------------------------------------------------
+constexpr int kRelBins = 4096;        // R + 1 must fit the LDS histogram
+constexpr int kRelTile = 4096;        // jobs per workgroup of the scatter
+
+__global__ __launch_bounds__(256) void rel_count_kernel(const int32_t *__restrict__ keys, int J, int bins, int32_t *__restrict__ hist,
+                                                        int32_t *__restrict__ next_pair) {
+    __shared__ int h[kRelBins];
+    if (blockIdx.x == 0)      // the histogram + cursor pair the NEXT call will use (the pairs alternate): no memset launch per step
+        for (int i = threadIdx.x; i < 2 * kRelBins; i += 256) next_pair[i] = 0;
+    for (int i = threadIdx.x; i < bins; i += 256) h[i] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * kRelTile + threadIdx.x; i < min(J, (blockIdx.x + 1) * kRelTile); i += 256) atomicAdd(&h[keys[i]], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += 256) if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+__global__ __launch_bounds__(256) void rel_scatter_kernel(const int32_t *__restrict__ keys, const int32_t *__restrict__ vals, int J, int R,
+                                                          int32_t *__restrict__ hist, int32_t *__restrict__ cursor,
+                                                          int32_t *__restrict__ sorted_vals, int32_t *__restrict__ bucket_start,
+                                                          int32_t *__restrict__ tile_rel, int32_t *__restrict__ tile_row0,
+                                                          int32_t *__restrict__ n_tiles, int tile_shift) {
+    const int bins = R + 1;
+    __shared__ int start[kRelBins + 1];      // exclusive scan of the histogram
+    __shared__ int cnt[kRelBins];            // this tile's histogram, then its base per bin
+    __shared__ int part[256];
+    // exclusive scan: 16 consecutive bins per thread, then the 256 partial sums
+    constexpr int PER = kRelBins / 256;
+    int local[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { const int i = threadIdx.x * PER + k; local[k] = i < bins ? hist[i] : 0; sum += local[k]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int add = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { const int i = threadIdx.x * PER + k; if (i <= kRelBins) start[i] = run; run += local[k]; }
+    if (threadIdx.x == 255) start[kRelBins] = run;
+    for (int i = threadIdx.x; i < bins; i += 256) cnt[i] = 0;
+    __syncthreads();
+    // this tile
+    constexpr int ITEMS = kRelTile / 256;
+    int key[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const int i = blockIdx.x * kRelTile + threadIdx.x + 256 * k;
+        key[k] = i < J ? keys[i] : -1;
+        rank[k] = key[k] >= 0 ? atomicAdd(&cnt[key[k]], 1) : 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += 256) { const int c = cnt[i]; cnt[i] = c ? start[i] + atomicAdd(&cursor[i], c) : 0; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const int i = blockIdx.x * kRelTile + threadIdx.x + 256 * k;
+        if (key[k] >= 0) sorted_vals[cnt[key[k]] + rank[k]] = vals[i];
+    }
+    if (blockIdx.x != 0) return;
+    // workgroup 0: bucket starts (bucket_start[r] = first position with key >= r, r = 0 .. R+1) and the tile map
+    for (int r = threadIdx.x; r <= R + 1; r += 256) bucket_start[r] = r <= R ? start[r] : J;
+    const int tile_rows = 1 << tile_shift;
+    int tiles_mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { const int r = threadIdx.x * PER + k; if (r < R) tiles_mine += (local[k] + tile_rows - 1) >> tile_shift; }
+    __syncthreads();
+    part[threadIdx.x] = tiles_mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int add = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int tix = part[threadIdx.x] - tiles_mine;
+    if (threadIdx.x == 255) n_tiles[0] = part[255];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int r = threadIdx.x * PER + k;
+        if (r < R)
+            for (int row = start[r]; row < start[r] + local[k]; row += tile_rows) { tile_rel[tix] = r; tile_row0[tix] = row; tix++; }
+    }
 }
 
 // predict: every triple uses the matrix of predict_r[0] (TransR.py:83): one bucket holding all slots
@@ -252,15 +347,20 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(GemmArgs a) {
 // the batch, a single owner per relation would serialise on it).
 constexpr int WG_TILES = 8;
 
+// sole = this workgroup's span holds the relation's WHOLE bucket: it is the only writer of its output block of g_M[r] (zero
+// on entry), so the partial is stored, not added with memory-side atomics (config #4's batch: 46 rows per relation, every
+// relation has one owner, and 38 MB of fp32 atomics per step become plain stores)
 __device__ __forceinline__ void wgrad_flush(const GemmArgs &a, float *__restrict__ g_mat, int r, int i0, int jg, int lane,
-                                            const f32x16 &acc) {
+                                            const f32x16 &acc, bool sole) {
     if (jg >= a.Dr) return;
     float *G = g_mat + (long long)r * a.De * a.Dr;
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) {
         const int ig = i0 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        if (ig < a.De)
-            __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(G + (long long)ig * a.Dr + jg), acc[reg]);
+        if (ig < a.De) {
+            if (sole) G[(long long)ig * a.Dr + jg] = acc[reg];
+            else __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(G + (long long)ig * a.Dr + jg), acc[reg]);
+        }
     }
 }
 
@@ -279,10 +379,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(GemmArgs a, float *__restric
     const int jg = j0 + wave * 32 + (lane & 31);
     f32x16 acc = {0};
     int r_cur = a.tile_rel[t0];
+    // rows [span_lo, span_hi) of the relation-sorted job list belong to this workgroup
+    const int span_lo = a.tile_row0[t0];
+    const int span_hi = a.tile_row0[t1 - 1] + min(tile_rows, a.bucket_start[a.tile_rel[t1 - 1] + 1] - a.tile_row0[t1 - 1]);
+#define KGE_SOLE(rel_) (a.bucket_start[rel_] >= span_lo && a.bucket_start[(rel_) + 1] <= span_hi)
     for (int t = t0; t < t1; t++) {
         const int r = a.tile_rel[t];
         if (r != r_cur) {
-            wgrad_flush(a, g_mat, r_cur, i0, jg, lane, acc);
+            wgrad_flush(a, g_mat, r_cur, i0, jg, lane, acc, KGE_SOLE(r_cur));
             acc = f32x16{0};
             r_cur = r;
         }
@@ -315,7 +419,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(GemmArgs a, float *__restric
             }
         }
     }
-    wgrad_flush(a, g_mat, r_cur, i0, jg, lane, acc);
+    wgrad_flush(a, g_mat, r_cur, i0, jg, lane, acc, KGE_SOLE(r_cur));
+#undef KGE_SOLE
 }
 
 
@@ -655,14 +760,28 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, stream, d_h, d_t, d_r, (long long)n_pos, (long long)n_neg,
                        (long long)stride, (int)m.negative_rel, (int)R, g_w.keys, g_w.vals, g_w.job_ent);
-    size_t tmp = g_w.sort_tmp_bytes;
-    rc = hip_check(rocprim::radix_sort_pairs(g_w.sort_tmp, tmp, g_w.keys, g_w.keys2, g_w.vals, g_w.vals2, (size_t)slots, 0,
-                                             bits_for(R), stream), "transr bucket sort");
-    if (rc) return rc;
     // v2 kernels (16x16x4 MFMA, 128-row tiles): dims multiples of 4 up to 208, one workgroup covers all columns
     const bool v2 = De % 4 == 0 && Dr % 4 == 0 && De >= 4 && Dr >= 4 && De <= LDB2 && Dr <= LDB2 && engine().transr_v1 != 1;
-    hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(1024), 0, stream, g_w.keys2, (int)slots, (int)R, g_w.bucket_start,
-                       g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, v2 ? 7 : 5);
+    if (R + 1 <= kRelBins && !engine().counts_force_sort) {
+        // two-launch counting sort by relation; bucket starts and the tile map come with it
+        if (!g_w.rel_hist) {
+            if ((rc = grow(g_w.rel_hist, 4 * (size_t)kRelBins, "transr relation histogram"))) return rc;
+            if ((rc = hip_check(hipMemset(g_w.rel_hist, 0, sizeof(int32_t) * 4 * kRelBins), "zero relation histogram"))) return rc;
+        }
+        int32_t *pair = g_w.rel_hist + (g_w.rel_parity ? 2 * kRelBins : 0), *other = g_w.rel_hist + (g_w.rel_parity ? 0 : 2 * kRelBins);
+        g_w.rel_parity ^= 1;
+        const unsigned tiles = (unsigned)((slots + kRelTile - 1) / kRelTile);
+        hipLaunchKernelGGL(rel_count_kernel, dim3(tiles), dim3(256), 0, stream, g_w.keys, (int)slots, (int)R + 1, pair, other);
+        hipLaunchKernelGGL(rel_scatter_kernel, dim3(tiles), dim3(256), 0, stream, g_w.keys, g_w.vals, (int)slots, (int)R, pair,
+                           pair + kRelBins, g_w.vals2, g_w.bucket_start, g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, v2 ? 7 : 5);
+    } else {
+        size_t tmp = g_w.sort_tmp_bytes;
+        rc = hip_check(rocprim::radix_sort_pairs(g_w.sort_tmp, tmp, g_w.keys, g_w.keys2, g_w.vals, g_w.vals2, (size_t)slots, 0,
+                                                 bits_for(R), stream), "transr bucket sort");
+        if (rc) return rc;
+        hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(1024), 0, stream, g_w.keys2, (int)slots, (int)R, g_w.bucket_start,
+                           g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, v2 ? 7 : 5);
+    }
     GemmArgs ga;
     ga.ent = tables[0]; ga.mat = tables[2]; ga.GP = g_w.GP; ga.P = g_w.P; ga.g_ent = grads[0];
     ga.sorted_slots = g_w.vals2; ga.job_ent = g_w.job_ent; ga.bucket_start = g_w.bucket_start;
