@@ -120,8 +120,8 @@ const char *kge_version(void);
  *   "hub_copies":        1 (default) = on the fp32-atomic TransH/TransD path, relation-side gradient rows that would
  *                        take >= 128 adds per step are accumulated in up to 64 copies and folded (same-address
  *                        atomics serialise); 0 = straight into the accumulators
- *   "transr_v1":         1 = TransR always on the 32x32x2 MFMA tiles, 2 = 16x16x4 tiles with the all-output-tiles
- *                        wgrad forced (test hooks; default 0 = automatic)
+ *   "transr_v1":         test hooks for the TransR MFMA tilings (default 0 = automatic): 1 = always the 32x32x2 tiles; 2 = 16x16x4
+ *                        tiles with the all-output-tiles wgrad and its 512-row spans forced; 3 = 16x16x4 tiles with the 32x32x2 wgrad
  *   "time_emit":         N > 0 = bracket every N-th launch of the TransE emit kernel with HIP events on its launch stream
  *   "fb_occ4":           1 (default) = TransH / TransD / TransR's vector stage at <= 4 elements per lane run the forward/backward body
  *                        compiled for four waves per SIMD (128 VGPRs); 0 = the uncapped build

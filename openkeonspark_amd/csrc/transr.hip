@@ -606,11 +606,13 @@ constexpr int WK2 = 16;                 // rows per staged chunk (4 k-steps)
 constexpr int WH2 = 7;                  // output row tiles per half
 constexpr int LDX2 = WH2 * 16;          // [row k][i] stride of the staged X half: 112 = 16 mod 32 banks
 
-__global__ __launch_bounds__(256, 2) void wgrad2_kernel(GemmArgs a, float *__restrict__ g_mat) {
+__global__ __launch_bounds__(256, 2) void wgrad2_kernel(GemmArgs a, float *__restrict__ g_mat, int span) {
+    // span: 128-row tiles per workgroup (SPAN2 = 512 rows between flushes for well-filled buckets; 1 at the reference's batch
+    // sizes, where a tile is one relation's whole bucket and the chip needs every tile as a workgroup of its own)
     const int n_tiles = a.n_tiles[0];
-    const int t0 = blockIdx.x * SPAN2;
+    const int t0 = blockIdx.x * span;
     if (t0 >= n_tiles) return;
-    const int t1 = min(t0 + SPAN2, n_tiles);
+    const int t1 = min(t0 + span, n_tiles);
     __shared__ __attribute__((aligned(16))) float Xs[WK2 * LDX2];    // [row k][i - i0]
     __shared__ __attribute__((aligned(16))) float Gs[WK2 * LDB2];    // [row k][j], stride 208
     const int tid = threadIdx.x, lane = tid & 63;
@@ -797,14 +799,18 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
                                     m.negative_rel, d_loss, stream);
     if (rc) return rc;
     if (v2) {
-        const dim3 wg((max_tiles + SPAN2 - 1) / SPAN2, 2);
         if (De <= 112) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 7>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
         else hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 13>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
         // the all-output-tiles wgrad (full 13 x 13 tile grid only) pays one 160 kB flush per relation change: only with
         // well-filled buckets (measured: 316 vs 400 us at 574 rows per relation, 131 vs 77 us at 46)
         const bool full_grid = De > 192 && Dr > 192;
-        if (full_grid && (slots >= 256 * R || engine().transr_v1 == 2)) {
-            hipLaunchKernelGGL(wgrad2_kernel, wg, dim3(256), 0, stream, ga, grads[2]);
+        const int opt = engine().transr_v1;
+        if (full_grid && opt != 3) {
+            // well-filled buckets: 512 rows between flushes; sparse buckets (a tile = one relation's whole bucket, stored by its
+            // single owner): one tile per workgroup so that every tile is in flight
+            const int span = (slots >= 256 * R || opt == 2) ? SPAN2 : 1;
+            const dim3 wg2((max_tiles + span - 1) / span, 2);
+            hipLaunchKernelGGL(wgrad2_kernel, wg2, dim3(256), 0, stream, ga, grads[2], span);
         } else {
             const int tiles_i1 = (De + 31) / 32;
             const int wgt = WG_TILES * 32 / RW2;   // the same 256 rows between flushes as with 32-row tiles

@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5
 KINK_TOL = 3e-7     # |e| below this: fp32 evaluations of e = h^ + r^ - t^ (|x^| <= 1) may disagree on its sign
+KINK_TOL_TRANSR = 1e-6   # ... where h^, t^ come out of a 200-term projection summed in different orders (MFMA tiles vs a scalar loop)
 
 
 def near_ties(orc, bh, bt, br, B, N, eps=2e-6):
@@ -76,7 +77,8 @@ def run_steps(con, kg, orc, B, n, alpha, steps, name, model, dims):
                 worst["grad"] = max(worst["grad"], float(diff[clean].max() / scale))
             if len(bad) or len(bad_u):
                 if kink is None:
-                    kink, n_el = near_kink_rows(model, start, bh, bt, br, B, n, dims[0], dims[1], tol=KINK_TOL)
+                    kink, n_el = near_kink_rows(model, start, bh, bt, br, B, n, dims[0], dims[1],
+                                                tol=KINK_TOL_TRANSR if model == "transr" else KINK_TOL)
                     worst["kink_elems"] += n_el
                 unexplained = (set(bad.tolist()) | set(bad_u.tolist())) - kink[k]
                 assert not unexplained, (name, step, k, sorted(unexplained)[:10], "rows outside 1e-5 with no |e| < KINK_TOL in their group")

@@ -97,13 +97,13 @@ CASES = [("transe", 300, 11, 16), ("transe", 300, 11, 100), ("transe", 200, 7, 2
 TRANSR_CASES = [(120, 9, 12, 8), (150, 7, 200, 200), (90, 5, 64, 100), (60, 4, 33, 50)]
 
 
-@pytest.fixture(params=["v2-16x16x4", "v2-wgrad-all-tiles", "v1-32x32x2"])
+@pytest.fixture(params=["v2-16x16x4", "v2-wgrad-all-tiles", "v2-wgrad-32x32x2", "v1-32x32x2"])
 def transr_tiles(request):
     """The MFMA tilings of the TransR projections: 16x16x4 / 128-row tiles (dims <= 208; its all-output-tiles wgrad
     is only chosen for well-filled buckets, so it is forced here) and 32x32x2 / 32-row tiles."""
     from openkeonspark_amd import _lib
     L = _lib.lib()
-    L.kge_set_option(b"transr_v1", {"v1-32x32x2": 1, "v2-wgrad-all-tiles": 2, "v2-16x16x4": 0}[request.param])
+    L.kge_set_option(b"transr_v1", {"v1-32x32x2": 1, "v2-wgrad-all-tiles": 2, "v2-wgrad-32x32x2": 3, "v2-16x16x4": 0}[request.param])
     yield request.param
     L.kge_set_option(b"transr_v1", 0)
 
