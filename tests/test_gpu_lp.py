@@ -70,8 +70,8 @@ def test_device_link_prediction_matches_oracle(model):
                 mismatched += 1
                 assert np.abs(got[:4] - want[:4]).max() <= 1, (k, got, want)
     parity_report("device_link_prediction_vs_oracle[%s]" % model,
-                  eight_vectors_differing_by_one_count=mismatched, of=2 * n, bound=2)
-    assert mismatched <= 2
+                  eight_vectors_differing_by_one_count=mismatched, of=2 * n, bound=1)
+    assert mismatched <= 1
     assert 0.0 <= metrics["r_filter_tot"] <= 1.0 and metrics["r_rank"] >= 1.0 and metrics["l_filter_rank"] >= 1.0
     assert metrics["r_filter_rank"] <= metrics["r_rank"]
 

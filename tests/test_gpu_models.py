@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5
 # carve-outs, each reported through parity_report with the count actually seen (bounds = the counts observed on MI355X
 # when they were last revised; a regression inside a bound still shows in gpurun_out/parity_counts.jsonl)
-SIGN_FLIP_ROWS_BOUND = 4     # rows of a table whose gradient carries one sign flip of an element within rounding of zero
-EXACT_COUNT_ROWS_BOUND = 2   # rows of the integer count image touched by a hinge within rounding of its switch point
+SIGN_FLIP_ROWS_BOUND = 2     # rows of a table whose gradient carries one sign flip of an element within rounding of zero (observed: <= 2)
+EXACT_COUNT_ROWS_BOUND = 0   # rows of the integer count image touched by a hinge within rounding of its switch point (observed: 0)
 
 
 def relerr(a, b):
@@ -199,10 +199,10 @@ def test_training_steps_match_oracle(model, opt, grad_path):
                 bad = np.abs(du_g - du_o) > 1e-3 * np.abs(du_o).max()
                 adam_bad[k] = max(adam_bad.get(k, 0), int(bad.sum()))
                 adam_worst = max(adam_worst, float(np.abs(du_g - du_o).max() / alpha))
-                assert bad.sum() <= max(3, 2e-3 * bad.size) and np.abs(du_g - du_o).max() <= 4 * alpha, (step, k, bad.sum())
+                assert bad.sum() <= 2 and np.abs(du_g - du_o).max() <= 0.01 * alpha, (step, k, bad.sum())
     if opt == "Adam":
         parity_report("training_steps_match_oracle[%s-Adam-%s]" % (model, grad_path), elements_outside_1e3_of_update=adam_bad,
-                      worst_in_steps_of_alpha=adam_worst, bound_elements="max(3, 0.2%)", bound_steps=4)
+                      worst_in_steps_of_alpha=adam_worst, bound_elements=2, bound_steps=0.01)
     assert con.global_step == 5
     for g in con.get_gradients().values():
         assert not g.any()  # accumulators are re-zeroed by the update kernels
@@ -335,8 +335,8 @@ def test_transe_sign_count_training_tracks_oracle(D, n, opt):
             bad = np.abs(du_g - du_o) > 1e-3 * np.abs(du_o).max()
             parity_report("transe_sign_count_training[D=%d n=%d Adam] %s" % (D, n, k), elements_outside_1e3_of_update=int(bad.sum()),
                           of_elements=int(bad.size), worst_in_steps_of_alpha=float(np.abs(du_g - du_o).max() / alpha),
-                          bound_elements="max(3, 0.2%)", bound_steps=4)
-            assert bad.sum() <= max(3, 2e-3 * bad.size) and np.abs(du_g - du_o).max() <= 4 * alpha, (k, bad.sum())
+                          bound_elements=12, bound_steps=0.1)
+            assert bad.sum() <= 12 and np.abs(du_g - du_o).max() <= 0.1 * alpha, (k, bad.sum())
 
 
 def test_transe_generic_path_still_matches_oracle():
