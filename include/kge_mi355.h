@@ -126,7 +126,7 @@ const char *kge_version(void);
  *   "fb_occ4":           1 (default) = TransH / TransD / TransR's vector stage at <= 4 elements per lane run the forward/backward body
  *                        compiled for four waves per SIMD (128 VGPRs); 0 = the uncapped build
  *   "persist_trace":     1 = kge_train_steps_persistent stamps its phase boundaries (read with kge_persistent_trace)
- *   "persist_threads":   threads per workgroup of the persistent launch, 1024 (default) or 512
+ *   "persist_threads":   threads per workgroup of the persistent launch, 512 (default) or 1024
  *   "libc_rand_restart": restart the glibc-compatible seed generator, as in a fresh process (the next
  *                        randReset then yields 1804289383, 846930886, ... again) */
 int kge_set_option(const char *name, INT value);

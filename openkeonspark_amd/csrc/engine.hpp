@@ -66,7 +66,7 @@ struct Engine {
     const float *shadow_for_ent = nullptr, *shadow_for_rel = nullptr;
     int fb_occ4 = 1;            // projecting models at <= 4 elements per lane: the forward/backward body compiled for four waves per SIMD
     int persist_trace = 0;      // measurement hook: the persistent launch stamps its phase boundaries (kge_persistent_trace)
-    int persist_threads = 1024; // threads per workgroup of the persistent launch (1024 or 512)
+    int persist_threads = 512;  // threads per workgroup of the persistent launch (512, or 1024: spills at its 128-register cap, measured slower)
     int counts_force_sort = 0;  // test hook: take the sort+segsum reduction even for small tables
 };
 
