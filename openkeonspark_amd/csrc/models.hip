@@ -507,6 +507,7 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
     constexpr int TEAMS = 256 / L;
     FbArgs a = a_in;
     const bool defer_pass = a.g_ent && a.g_rel;   // residual accumulators given: deferred groups get the fp32 pass
+    guard_loss_stream(stream);
     if (!defer_pass) { a.loss_out = d_loss; a.loss_ticket = engine().dev.loss_ticket; }   // the emit kernel's last block writes the loss
     long long blocks = (a.n_pos + TEAMS - 1) / TEAMS;
     if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
@@ -544,6 +545,16 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
     d.loss_partials = a.loss_partials + blocks;
     hipLaunchKernelGGL((fwdbwd_kernel<KGE_TRANSE, L, C>), dim3(kDeferBlocks), dim3(256), 0, stream, d);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, a.loss_partials, (int)blocks + kDeferBlocks, a.unit, d_loss);
+}
+
+// The per-workgroup loss partials and the "last workgroup" tickets are ONE process-global set of buffers: two loss-producing
+// kernels in flight on different streams would interleave tickets and partials.  A launch on another stream than the previous
+// one therefore waits for that stream first (the training loop uses one stream: this never triggers there).
+void guard_loss_stream(hipStream_t stream) {
+    static hipStream_t last = nullptr;
+    static bool have = false;
+    if (have && last != stream) (void)hipStreamSynchronize(last);
+    last = stream; have = true;
 }
 
 int ensure_loss_buffers() {
@@ -643,6 +654,7 @@ static void launch_fb(const FbArgs &a, float *d_loss, hipStream_t stream) {
     if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
     if (blocks < 1) blocks = 1;
     FbArgs f = a;
+    guard_loss_stream(stream);
     f.loss_out = d_loss; f.loss_ticket = engine().dev.loss_ticket;   // the last block writes the loss
     if constexpr (MODEL != KGE_TRANSE && C <= 4) {
         if (engine().fb_occ4) { hipLaunchKernelGGL((fwdbwd_kernel_occ4<MODEL, L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, f); return; }
@@ -657,6 +669,7 @@ static void launch_fb_records(const FbArgs &a, float *d_loss, hipStream_t stream
     if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
     if (blocks < 1) blocks = 1;
     FbArgs f = a;
+    guard_loss_stream(stream);
     f.loss_out = d_loss; f.loss_ticket = engine().dev.loss_ticket;
     if constexpr ((MODEL == KGE_TRANSH || MODEL == KGE_TRANSD) && C <= 4) {
         if (engine().fb_occ4) { hipLaunchKernelGGL((fwdbwd_kernel_occ4<MODEL, L, C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, f); return; }

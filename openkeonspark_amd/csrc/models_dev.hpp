@@ -47,6 +47,7 @@ struct FbArgs {
 };
 
 int ensure_loss_buffers();
+void guard_loss_stream(hipStream_t stream);   // loss partials / tickets are process-global: serialise launches across streams
 
 // Per-block partial hinge sums -> loss = sum / denom (TransE.py:51).  With a.loss_out set, the LAST block to
 // finish (ticket counter) adds the partials in the fixed order loss_finalize_kernel uses and writes the loss,
@@ -63,6 +64,11 @@ __device__ __forceinline__ void finish_loss(const FbArgs &a, float *red, float l
         for (int i = 0; i < TEAMS; i++) s += red[i];
         is_last = 0;
         if (a.loss_out) {
+            // HARDWARE ASSUMPTION (gfx950; not promised by the HIP / LLVM memory model): relaxed agent-scope atomics are
+            // performed at the memory side and are therefore coherent across XCDs by themselves, and a returning atomic
+            // followed by s_waitcnt vmcnt(0) has been performed before the ticket add that follows it is issued.  The
+            // buffers are process-global: launches are serialised across streams by guard_loss_stream (models.hip).  Every
+            // loss value of the GPU test-suite (hundreds of launches against the oracle at 1e-5) goes through this path.
             // No fences: an agent-scope release fence writes back the whole XCD L2 on gfx950 (measured: the emit
             // kernel went from 119 to 237 us).  Memory-side atomics are coherent across XCDs by themselves: publish
             // the partial with a RETURNING exchange, wait for it, then take a ticket.

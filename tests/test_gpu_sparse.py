@@ -166,3 +166,17 @@ def test_fused_reduce_apply_equals_two_stage(dim, n_neg):
     assert runs[0][0] == runs[1][0]
     for a, b in zip(runs[0][1], runs[1][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("model,opt,n_neg", [("TransH", "SGD", 1), ("TransE", "Adam", 1), ("TransE", "SGD", 64)])
+def test_sparse_rows_request_that_cannot_be_honoured_raises(model, opt, n_neg):
+    """sparse_rows=True needs TransE on the sign-count path (1..63 negatives) with SGD; anything else must fail loudly instead of
+    silently allocating dense gradient / count / Adam images."""
+    import openkeonspark_amd as ok
+    con = ok.Config()
+    con.set_in_path(os.path.join(GOLD, "kg_tiny") + "/")
+    con.set_work_threads(2); con.set_nbatches(2); con.set_dimension(16); con.set_ent_neg_rate(n_neg); con.set_opt_method(opt)
+    con.sparse_rows = True
+    con.init()
+    with pytest.raises(ok.KgeError):
+        con.set_model_and_session(getattr(ok, model))
