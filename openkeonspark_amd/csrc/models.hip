@@ -429,20 +429,21 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
                         cnt++; lsum += v;
                         const long long m = (long long)(3 + k0 + kk + u) * a.n_pos + b;
                         uint32_t rec[Q];
+                        // new head (0): dL/dx^ = -s, kept t gets +s, r gets -s;  new tail (1): +s, kept h gets -s, r gets -s;
+                        // new relation vector (2): -s, h gets -s, t gets +s.  Branch-free: the three cases differ only in small
+                        // integer multipliers (uniform per negative), so the accumulators take packed multiply-adds instead of
+                        // three code paths whose merges cost a register move per accumulator
+                        const int c = code[u];
+                        const s16x2 kh = pack16(c == 0 ? 0 : -1, c == 0 ? 0 : -1), kt = pack16(c == 1 ? 0 : 1, c == 1 ? 0 : 1);
+                        const s16x2 kr = pack16(c == 2 ? 0 : -1, c == 2 ? 0 : -1), kx = pack16(c == 1 ? 1 : -1, c == 1 ? 1 : -1);
 #pragma unroll
                         for (int q = 0; q < Q; q++) {
                             const s16x2 s_lo = pack16(sign_of_bits(x[u][q].x), sign_of_bits(x[u][q].y));
                             const s16x2 s_hi = pack16(sign_of_bits(x[u][q].z), sign_of_bits(x[u][q].w));
-                            if (code[u] == 0) {         // new head: dL/dx^ = -s ; kept t gets +s, r gets -s
-                                rec[q] = bytes_of(-s_lo, -s_hi);
-                                At_lo[q] += s_lo; At_hi[q] += s_hi; Ar_lo[q] -= s_lo; Ar_hi[q] -= s_hi;
-                            } else if (code[u] == 1) {  // new tail: +s ; kept h gets -s, r gets -s
-                                rec[q] = bytes_of(s_lo, s_hi);
-                                Ah_lo[q] -= s_lo; Ah_hi[q] -= s_hi; Ar_lo[q] -= s_lo; Ar_hi[q] -= s_hi;
-                            } else {                    // new relation vector: -s ; h gets -s, t gets +s
-                                rec[q] = bytes_of(-s_lo, -s_hi);
-                                Ah_lo[q] -= s_lo; Ah_hi[q] -= s_hi; At_lo[q] += s_lo; At_hi[q] += s_hi;
-                            }
+                            rec[q] = bytes_of(s_lo * kx, s_hi * kx);
+                            Ah_lo[q] += s_lo * kh; Ah_hi[q] += s_hi * kh;
+                            At_lo[q] += s_lo * kt; At_hi[q] += s_hi * kt;
+                            Ar_lo[q] += s_lo * kr; Ar_hi[q] += s_hi * kr;
                         }
                         store_record<L, Q>(a, lane, m, rec);
                         if (lane == kk + u) my_dst = code[u] == 2 ? a.ent_total + row[u] : row[u];
