@@ -125,6 +125,9 @@ const char *kge_version(void);
  *   "time_emit":         N > 0 = bracket every N-th launch of the TransE emit kernel with HIP events on its launch stream
  *   "fb_occ4":           1 (default) = TransH / TransD / TransR's vector stage at <= 4 elements per lane run the forward/backward body
  *                        compiled for four waves per SIMD (128 VGPRs); 0 = the uncapped build
+ *   "persist_touch":     1 = the persistent launch requests all rows of a group together before its dependent gathers (default 0:
+ *                        measured, no gain -- the phase is bound by same-address atomics, not by cold gathers)
+ *   "persist_ahead":     1 (default) = teams without a group draw the next batch during the forward/backward phase
  *   "persist_trace":     1 = kge_train_steps_persistent stamps its phase boundaries (read with kge_persistent_trace)
  *   "persist_threads":   threads per workgroup of the persistent launch, 512 (default) or 1024
  *   "libc_rand_restart": restart the glibc-compatible seed generator, as in a fresh process (the next

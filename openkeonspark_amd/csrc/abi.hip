@@ -226,6 +226,8 @@ int kge_set_option(const char *name, INT value) {
     if (n == "transr_v1") { engine().transr_v1 = (int)value; return KGE_OK; }
     if (n == "time_emit") { engine().time_emit = value > 0 ? (int)value : 0; if (value > 0) { engine().emit_launches = 0; engine().emit_seen = 0; } return KGE_OK; }
     if (n == "fb_occ4") { engine().fb_occ4 = value != 0; return KGE_OK; }
+    if (n == "persist_ahead") { engine().persist_ahead = value != 0; return KGE_OK; }
+    if (n == "persist_touch") { engine().persist_touch = value != 0; return KGE_OK; }
     if (n == "persist_trace") { engine().persist_trace = value != 0; return KGE_OK; }
     if (n == "persist_threads") { engine().persist_threads = value == 1024 ? 1024 : 512; return KGE_OK; }
     if (n == "libc_rand_restart") { engine().libc = LibcRand(); return KGE_OK; }  // as in a fresh process

@@ -65,6 +65,8 @@ struct Engine {
     uint16_t *shadow_ent = nullptr, *shadow_rel = nullptr;
     const float *shadow_for_ent = nullptr, *shadow_for_rel = nullptr;
     int fb_occ4 = 1;            // projecting models at <= 4 elements per lane: the forward/backward body compiled for four waves per SIMD
+    int persist_ahead = 1;      // persistent launch: idle teams sample the next batch during the forward/backward phase
+    int persist_touch = 0;      // persistent launch: a group's rows requested together before its dependent gathers (measured: no gain)
     int persist_trace = 0;      // measurement hook: the persistent launch stamps its phase boundaries (kge_persistent_trace)
     int persist_threads = 512;  // threads per workgroup of the persistent launch (512, or 1024: spills at its 128-register cap, measured slower)
     int counts_force_sort = 0;  // test hook: take the sort+segsum reduction even for small tables

@@ -284,11 +284,24 @@ def main_fun(argv):
     t0 = time.time()
     g = last_global_step
     while g < iterations:
-        loss = con.train_step()
-        g = con.global_step
-        if rank == 0:
-            print('Global step: {} Epoch: {} Batch: {} loss: {}'.format(
-                g, int((g - last_global_step) / con.nbatches), int((g - last_global_step) % con.nbatches), loss))
+        if not distributed and con.persistent_supported():
+            # launch-latency-bound step sizes: every step up to the next checkpoint / early-stop check in ONE persistent launch
+            # (csrc/persist.hip); the per-step log lines of distribute_training.py:283 are printed from the returned losses
+            to_epoch = con.nbatches - (g - last_global_step) % con.nbatches
+            chunk = min(iterations - g, to_epoch, max(to_reach_step - g, 1) if g < to_reach_step else to_epoch)
+            losses = con.train_steps(chunk)
+            for i, l in enumerate(losses):
+                gi = g + i + 1
+                print('Global step: {} Epoch: {} Batch: {} loss: {}'.format(
+                    gi, int((gi - last_global_step) / con.nbatches), int((gi - last_global_step) % con.nbatches), float(l)))
+            loss = float(losses[-1])
+            g = con.global_step
+        else:
+            loss = con.train_step()
+            g = con.global_step
+            if rank == 0:
+                print('Global step: {} Epoch: {} Batch: {} loss: {}'.format(
+                    g, int((g - last_global_step) / con.nbatches), int((g - last_global_step) % con.nbatches), loss))
         if (g - last_global_step) % con.nbatches == 0 and argv.output_path:
             save_checkpoint(con, argv.output_path, max_to_keep=patience + 5, write=rank == 0)
         if g < iterations and g >= to_reach_step:

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(name, spec, model, dim, n, threads, steps=200):
+def run(name, spec, model, dim, n, threads, steps=200, touch=0, ahead=1):
     import torch
     import openkeonspark_amd as pkg
     from openkeonspark_amd.synthetic import make_dataset
@@ -18,6 +18,8 @@ def run(name, spec, model, dim, n, threads, steps=200):
     con.set_model_and_session(getattr(pkg, model))
     L = con.lib
     L.kge_set_option(b"persist_threads", threads)
+    L.kge_set_option(b"persist_touch", touch)
+    L.kge_set_option(b"persist_ahead", ahead)
     con.train_steps(20, persistent=True)
     L.kge_set_option(b"persist_trace", 1)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -31,7 +33,7 @@ def run(name, spec, model, dim, n, threads, steps=200):
     us = lambda a: float(np.median(a)) / 100.0
     body = tr[2:steps - 1]
     nxt = tr[3:steps, 0]
-    out = {"config": name, "threads": threads, "batch": con.batch_size, "us_per_step_wall": dt / steps * 1e6,
+    out = {"config": name, "threads": threads, "touch": touch, "ahead": ahead, "batch": con.batch_size, "us_per_step_wall": dt / steps * 1e6,
            "sweep": us(body[:, 1] - body[:, 0]), "sampling": us(body[:, 2] - body[:, 1]), "barrier1": us(body[:, 3] - body[:, 2]),
            "fwdbwd": us(body[:, 4] - body[:, 3]), "barrier2": us(body[:, 5] - body[:, 4]), "step_by_stamps": us(nxt - body[:, 0]),
            "fwdbwd_per_block_us": {"min": float(per_block.min()), "p50": float(np.median(per_block)), "p90": float(np.percentile(per_block, 90)),
@@ -42,6 +44,5 @@ def run(name, spec, model, dim, n, threads, steps=200):
 if __name__ == "__main__":
     from openkeonspark_amd.synthetic import FB15K237, WN18RR
     fb = dict(FB15K237, name="fb15k237_shaped"); wn = dict(WN18RR, name="wn18rr_shaped")
-    for threads in (1024, 512):
-        run("#1 FB15k-237 TransE D=100 n=1 B=2721", fb, "TransE", 100, 1, threads)
-        run("#3 WN18RR TransH D=200 n=1 B=8683", wn, "TransH", 200, 1, threads)
+    run("#1 FB15k-237 TransE D=100 n=1 B=2721", fb, "TransE", 100, 1, 512)
+    run("#3 WN18RR TransH D=200 n=1 B=8683", wn, "TransH", 200, 1, 512)
