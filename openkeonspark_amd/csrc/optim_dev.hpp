@@ -11,18 +11,34 @@ struct SweepTables {
     long long n[4];
 };
 
-// p -= lr * g; g = 0 over one table, threads tid, tid + stride, ... (16 B per lane; untouched 16-byte groups are skipped)
+// p -= lr * g; g = 0 over one table, threads tid, tid + stride, ... (16 B per lane; untouched 16-byte groups are skipped).
+// U groups per thread are loaded before any is processed (U x 16 B in flight per lane): the one-launch kernel has enough
+// threads to cover the memory latency with U = 1; the persistent launch (one workgroup per CU) needs the bytes in flight per
+// thread instead.  Same arithmetic per element whatever U.
+template <int U = 1>
 __device__ __forceinline__ void sgd_sweep(float *__restrict__ p, float *__restrict__ g, long long n, float lr, long long tid, long long stride) {
     const long long n4 = n >> 2;
     float4 *p4 = reinterpret_cast<float4 *>(p);
     float4 *g4 = reinterpret_cast<float4 *>(g);
-    for (long long i = tid; i < n4; i += stride) {
-        float4 gv = g4[i];
-        if (gv.x != 0.f || gv.y != 0.f || gv.z != 0.f || gv.w != 0.f) {  // untouched rows: p - lr*0 == p, skip the stores
-            float4 pv = p4[i];
-            pv.x -= lr * gv.x; pv.y -= lr * gv.y; pv.z -= lr * gv.z; pv.w -= lr * gv.w;
-            p4[i] = pv;
-            g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long i0 = tid; i0 < n4; i0 += stride * U) {
+        float4 gv[U], pv[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long long i = i0 + stride * u;
+            gv[u] = g4[i < n4 ? i : i0];
+            live[u] = i < n4 && (gv[u].x != 0.f || gv[u].y != 0.f || gv[u].z != 0.f || gv[u].w != 0.f);  // untouched rows: p - lr*0 == p, skip the stores
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) pv[u] = p4[live[u] ? i0 + stride * u : i0];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (live[u]) {
+                const long long i = i0 + stride * u;
+                pv[u].x -= lr * gv[u].x; pv[u].y -= lr * gv[u].y; pv[u].z -= lr * gv[u].z; pv[u].w -= lr * gv[u].w;
+                p4[i] = pv[u];
+                g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     }
     for (long long i = (n4 << 2) + tid; i < n; i += stride) {

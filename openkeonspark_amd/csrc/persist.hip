@@ -233,7 +233,7 @@ __global__ __launch_bounds__(THREADS) void persistent_steps_kernel(PersistArgs p
             for (int i = 0; i < pa.n_tables; i++) {
                 if (pa.fold_k > 1 && (i == 1 || i == 2)) continue;
                 if (pa.adam) adam_sweep(pa.tb.p[i], pa.tb.m[i], pa.tb.v[i], pa.tb.g[i], pa.tb.n[i], lr, pa.b1, pa.b2, pa.eps, tid, stride);
-                else sgd_sweep(pa.tb.p[i], pa.tb.g[i], pa.tb.n[i], lr, tid, stride);
+                else sgd_sweep<4>(pa.tb.p[i], pa.tb.g[i], pa.tb.n[i], lr, tid, stride);
             }
             if (blockIdx.x == 0 && threadIdx.x < 64) {     // fixed-order sum of the workgroups' hinge sums (TransE.py:51)
                 const float *part = pa.partials + (long long)((step - 1) & 1) * gridDim.x;
