@@ -256,3 +256,55 @@ def test_two_rank_resume_equals_uninterrupted_run(tmp_path):
     assert int(first["step"]) == 10 and int(second["step"]) == 20 and int(full["step"]) == 20
     for k in full.files:
         assert np.array_equal(second[k], full[k]), k
+
+
+def _config5_worker(rank, world, port, out_dir):
+    """configs[4]'s regime at a reduced entity count: 200 k entities x dim 512 (0.4 GB table), B = 50 000, n = 1, sparse rows."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import openkeonspark_amd as pkg
+    pkg._lib.lib().kge_set_option(b"inv_table_max_bytes", 0)
+    rng = np.random.default_rng(5)
+    E, R, n_tr = 200_000, 500, 1_000_000
+    h = rng.integers(0, E, n_tr); t = rng.integers(0, E, n_tr); r = rng.integers(0, R, n_tr)
+    con = pkg.Config()
+    con.prefetch_sampling = False
+    con.set_work_threads(8); con.set_bern(1); con.set_dimension(512); con.set_ent_neg_rate(1); con.set_alpha(0.5)
+    con.set_opt_method("SGD"); con.set_nbatches(20)
+    con.sparse_rows = True
+    con.init_from_arrays(E, R, h, t, r)
+    con.set_model_and_session(pkg.TransE)
+    if world > 1:
+        con.init_distributed()
+        assert con._tables[0].shape[0] == E // world          # the entity table is sharded, not replicated
+    losses = [con.train_step() for _ in range(3)]
+    ent = con.get_parameters_by_name("ent_embeddings")        # collective: gathers the shards
+    rel = con.get_parameters_by_name("rel_embeddings")
+    torch.cuda.synchronize()
+    if rank == 0:
+        # a digest instead of the 0.4 GB table: row sums in float64 are order-free and see every element
+        np.savez(os.path.join(out_dir, "c5_w%d.npz" % world), losses=np.array(losses), ent_rowsum=ent.astype(np.float64).sum(1),
+                 ent_sample=ent[::997].copy(), rel=rel, states=con.get_stream_states())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_config5_regime_two_ranks_sharded_equals_one_rank(tmp_path):
+    """The table-sharded path at configs[4]'s shape (dim 512, uniform popularity, one negative): 2 ranks, each holding half of the
+    entity rows and exchanging rows / int8 records by all-to-all, end with the single-process tables bit for bit (the one-rank
+    step itself is checked against the oracle at this size in tests/test_gpu_configs.py)."""
+    import torch.multiprocessing as mp
+    port = 30700 + os.getpid() % 1000
+    for i, w in enumerate((1, 2)):
+        mp.start_processes(_config5_worker, args=(w, port + i, str(tmp_path)), nprocs=w, join=True, start_method="spawn")
+    one, two = np.load(str(tmp_path / "c5_w1.npz")), np.load(str(tmp_path / "c5_w2.npz"))
+    assert np.array_equal(one["states"], two["states"])
+    assert np.allclose(one["losses"], two["losses"], rtol=2e-5, atol=0)
+    assert np.array_equal(one["ent_rowsum"], two["ent_rowsum"]) and np.array_equal(one["ent_sample"], two["ent_sample"])
+    assert np.array_equal(one["rel"], two["rel"])
