@@ -33,7 +33,10 @@ def run(name, spec, model, dim, n, threads, steps=200, touch=0, ahead=1):
     us = lambda a: float(np.median(a)) / 100.0
     body = tr[2:steps - 1]
     nxt = tr[3:steps, 0]
-    out = {"config": name, "threads": threads, "touch": touch, "ahead": ahead, "batch": con.batch_size, "us_per_step_wall": dt / steps * 1e6,
+    U = {"TransE": 3 + n, "TransH": 4 + n, "TransD": 6 + 2 * n}[model]
+    alg = (2 * U * dim * 4 + 12 * (1 + n)) * con.batch_size      # every touched row read and written once + the ids
+    out = {"config": name, "step_algorithmic_bytes": alg, "step_algorithmic_GBps": alg / (dt / steps) / 1e9,
+           "step_frac_of_8TBps": alg / (dt / steps) / 8e12, "threads": threads, "touch": touch, "ahead": ahead, "batch": con.batch_size, "us_per_step_wall": dt / steps * 1e6,
            "sweep": us(body[:, 1] - body[:, 0]), "sampling": us(body[:, 2] - body[:, 1]), "barrier1": us(body[:, 3] - body[:, 2]),
            "fwdbwd": us(body[:, 4] - body[:, 3]), "barrier2": us(body[:, 5] - body[:, 4]), "step_by_stamps": us(nxt - body[:, 0]),
            "fwdbwd_per_block_us": {"min": float(per_block.min()), "p50": float(np.median(per_block)), "p90": float(np.percentile(per_block, 90)),
