@@ -63,6 +63,8 @@ def parse_args(argv=None):
     p.add_argument("--test_head", type=int, default=0)
     p.add_argument("--work_threads", type=int, default=8, help="virtual sampler threads (Config.py:65 hard-codes 8)")
     p.add_argument("--seed", type=int, default=0, help="parameter initialisation seed")
+    p.add_argument("--sparse_rows", type=int, default=-1, help="1 / 0: force / forbid the sparse touched-row TransE path (default: automatic "
+                                                             "above 8 GB of tables); on N ranks its entity table is sharded by row range")
     return p.parse_args(argv)
 
 
@@ -91,6 +93,8 @@ def get_conf(argv):
     con.set_opt_method(argv.optimizer)
     con.set_work_threads(getattr(argv, "work_threads", 8))
     con.seed = getattr(argv, "seed", 0)
+    if getattr(argv, "sparse_rows", -1) >= 0:
+        con.sparse_rows = bool(argv.sparse_rows)
     con.init()
     name = argv.model.lower()
     con.set_model({"transh": TransH, "transr": TransR, "transd": TransD}.get(name, TransE))
@@ -117,12 +121,20 @@ def get_last_step(output_path):
     return last_global_step
 
 
+def _sharded(con):
+    return con.world_size > 1 and getattr(con, "sparse_rows", False) and hasattr(con, "_shard")
+
+
 def checkpoint_arrays(con):
     """Variables under the reference's names, Adam slots as `<var>/Adam`, `<var>/Adam_1`
     (main_spark.py:74-98), plus the optimiser scalars and the sampler's rng streams.  COLLECTIVE in data-parallel
-    runs (owner-kept Adam slots and sharded tables are gathered): every rank calls it, rank 0 writes."""
+    runs (owner-kept Adam slots are gathered): every rank calls it, rank 0 writes.  A SHARDED entity table (the
+    table-sharded sparse mode) is not gathered: every rank writes its own rows beside the main file (save_checkpoint)."""
     con.sync_optimizer_state()
-    out = dict(con.get_parameters())
+    if _sharded(con):
+        out = {n: t.detach().cpu().numpy() for n, t in con.trainModel.parameter_lists.items() if n != "ent_embeddings"}
+    else:
+        out = dict(con.get_parameters())
     if con._adam:
         for name, m, v in zip(con.trainModel.table_names, con._adam_m, con._adam_v):
             out[name + "/Adam"] = m.detach().cpu().numpy()
@@ -136,21 +148,49 @@ def checkpoint_arrays(con):
     return out
 
 
+def _step_of(path):
+    return int(os.path.basename(path).split("model.ckpt-")[1].split(".")[0])
+
+
 def save_checkpoint(con, output_path, max_to_keep=10, write=True):
     arrays = checkpoint_arrays(con)
+    step = con.global_step
+    base = os.path.join(output_path, "model.ckpt-%d" % step)
+    if _sharded(con):      # this rank's rows of the entity table: model.ckpt-<step>.shard<g>of<N>.npz
+        os.makedirs(output_path, exist_ok=True)
+        sh = con._shard
+        rows = con.trainModel.parameter_lists["ent_embeddings"][:sh["hi"] - sh["lo"]].detach().cpu().numpy()
+        np.savez(base + ".shard%dof%d.npz" % (con.rank, con.world_size), rows=rows, lo=np.int64(sh["lo"]), hi=np.int64(sh["hi"]),
+                 ent_total=np.int64(con.entTotal))
     if not write:
         return None
     os.makedirs(output_path, exist_ok=True)
-    step = con.global_step
-    base = os.path.join(output_path, "model.ckpt-%d" % step)
     np.savez(base + ".npz", **{k.replace("/", "__"): v for k, v in arrays.items()})
     with open(os.path.join(output_path, "checkpoint"), "w") as f:
         f.write('model_checkpoint_path: "%s"\n' % base)
-    kept = sorted(glob.glob(os.path.join(output_path, "model.ckpt-*.npz")),
-                  key=lambda p: int(p.rsplit("-", 1)[1][:-4]))
+    kept = sorted((p for p in glob.glob(os.path.join(output_path, "model.ckpt-*.npz")) if ".shard" not in p), key=_step_of)
     for old in kept[:-max_to_keep]:
+        for part in glob.glob(old[:-4] + ".shard*of*.npz"):
+            os.remove(part)
         os.remove(old)
     return base + ".npz"
+
+
+def read_entity_rows(base, lo, hi, dim):
+    """Rows [lo, hi) of the entity table of a sharded checkpoint, from whichever shard files hold them (the number of ranks
+    may differ from the run that wrote them)."""
+    out = np.zeros((hi - lo, dim), np.float32)
+    got = 0
+    for part in sorted(glob.glob(base + ".shard*of*.npz")):
+        z = np.load(part)
+        plo, phi = int(z["lo"]), int(z["hi"])
+        a, b = max(lo, plo), min(hi, phi)
+        if a < b:
+            out[a - lo:b - lo] = z["rows"][a - plo:b - plo]
+            got += b - a
+    if got != hi - lo:
+        raise ValueError("sharded checkpoint %s: entity rows [%d, %d) are not all present in its shard files" % (base, lo, hi))
+    return out
 
 
 def grow_table(table, rows, rng, zeros=False):
@@ -178,6 +218,16 @@ def restore_checkpoint(con, path, allow_growth=True, arrays=None):
     shapes = con.trainModel.table_shapes()
     for i, name in enumerate(con.trainModel.table_names):
         rows = shapes[name][0]
+        if name not in z:      # a sharded checkpoint: the entity rows live in per-rank shard files beside the main file
+            base = path[:-4] if path.endswith(".npz") else path
+            if _sharded(con):
+                sh = con._shard
+                if sh["hi"] > sh["lo"]:
+                    part = read_entity_rows(base, sh["lo"], sh["hi"], shapes[name][1])
+                    con.trainModel.parameter_lists[name][:sh["hi"] - sh["lo"]].copy_(torch.from_numpy(part))
+            else:
+                con.set_parameters_by_name(name, read_entity_rows(base, 0, rows, shapes[name][1]))
+            continue
         tab = z[name]
         if tab.shape[0] != rows:
             if not allow_growth or tab.shape[0] > rows:
@@ -243,7 +293,8 @@ def main_fun(argv):
             local_rank = 0        # rehearsal of the multi-rank path on a one-GPU box (with KGE_DIST_BACKEND=gloo)
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if not dist.is_initialized():
+        own_group = not dist.is_initialized()       # a caller that brought its own process group keeps it afterwards
+        if own_group:
             dist.init_process_group(os.environ.get("KGE_DIST_BACKEND", "nccl"))   # "nccl" is RCCL on ROCm
     con = get_conf(argv)
     con.device = "cuda:%d" % torch.cuda.current_device()
@@ -342,7 +393,8 @@ def main_fun(argv):
     if distributed:
         import torch.distributed as dist
         dist.barrier()
-        dist.destroy_process_group()
+        if own_group:
+            dist.destroy_process_group()
     return con
 
 

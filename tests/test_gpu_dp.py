@@ -225,7 +225,7 @@ def test_cli_driver_under_two_ranks(tmp_path):
         assert abs(m1[k] - m2[k]) <= 1e-12 * max(1.0, abs(m1[k])), k
 
 
-def _resume_worker(rank, world, port, out_dir, run, train_times):
+def _resume_worker(rank, world, port, out_dir, run, train_times, sparse=False):
     sys.path.insert(0, ROOT)
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
                        "LOCAL_RANK": str(rank), "KGE_SINGLE_DEVICE": "1", "KGE_DIST_BACKEND": "gloo",
@@ -235,9 +235,20 @@ def _resume_worker(rank, world, port, out_dir, run, train_times):
     args = ["--input_path", os.path.join(GOLDEN, "kg_small"), "--output_path", os.path.join(out_dir, run),
             "--embedding_dimension", "32", "--n_mini_batches", "5", "--ent_neg_rate", "3", "--alpha", "0.01",
             "--optimizer", "Adam", "--bern_flag", "1", "--train_times", str(train_times)]
+    if sparse:      # the table-sharded sparse mode: SGD, per-rank shard files beside the checkpoint
+        args[args.index("--optimizer") + 1] = "SGD"
+        args += ["--sparse_rows", "1"]
+        from openkeonspark_amd import _lib
+        _lib.lib().kge_set_option(b"inv_table_max_bytes", 0)
+    if sparse:      # gathering the sharded table afterwards is a collective: keep the process group beyond main_fun
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     con = dt.main_fun(dt.parse_args(args))
     assert con.prefetch_sampling                      # the data-parallel default: batch i+1 is drawn during step i
+    assert (not sparse) or (con.sparse_rows and con._tables[0].shape[0] == 500)
     np.savez(os.path.join(out_dir, "%s_t%d_r%d.npz" % (run, train_times, rank)), step=con.global_step, **con.get_parameters())
+    if sparse:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def test_two_rank_resume_equals_uninterrupted_run(tmp_path):
@@ -308,3 +319,22 @@ def test_config5_regime_two_ranks_sharded_equals_one_rank(tmp_path):
     assert np.allclose(one["losses"], two["losses"], rtol=2e-5, atol=0)
     assert np.array_equal(one["ent_rowsum"], two["ent_rowsum"]) and np.array_equal(one["ent_sample"], two["ent_sample"])
     assert np.array_equal(one["rel"], two["rel"])
+
+
+def test_two_rank_sharded_checkpoint_and_resume(tmp_path):
+    """The table-sharded sparse mode under the driver: every rank writes its rows of the entity table beside the checkpoint
+    (model.ckpt-<step>.shard<g>of<N>.npz), a resumed 2-rank run reads them back, and ends with the tables of the uninterrupted
+    run bit for bit."""
+    import torch.multiprocessing as mp
+    port = 30900 + os.getpid() % 1000
+    for i, (run, times) in enumerate((("full", 4), ("split", 2), ("split", 2))):
+        mp.start_processes(_resume_worker, args=(2, port + i, str(tmp_path), run, times, True), nprocs=2, join=True, start_method="spawn")
+        if run == "split" and i == 1:
+            os.rename(str(tmp_path / "split_t2_r0.npz"), str(tmp_path / "split_first_r0.npz"))
+            parts = sorted(f for f in os.listdir(str(tmp_path / "split")) if ".shard" in f and "ckpt-10." in f)
+            assert parts == ["model.ckpt-10.shard0of2.npz", "model.ckpt-10.shard1of2.npz"]
+    full = np.load(str(tmp_path / "full_t4_r0.npz"))
+    second = np.load(str(tmp_path / "split_t2_r0.npz"))
+    assert int(second["step"]) == 20 and int(full["step"]) == 20
+    for k in full.files:
+        assert np.array_equal(second[k], full[k]), k
