@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict_
     int cur = keys[start];
     int cur_row = uidx ? uidx[start] : cur;
     bool first_run = true;
-    constexpr int U = 8;  // records in flight per team
+    constexpr int U = 16;  // records in flight per team
     for (int i0 = 0; i0 < n; i0 += U) {
         int k[U], id[U], ur[U];
         uint32_t w[U][Q];
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void segsum_f32_kernel(const float *__restrict
                                                          const int32_t *__restrict__ ids, const int32_t *__restrict__ n_valid_p,
                                                          FloatRowSpace rs, int D, int chunk_len) {
     constexpr int TEAMS = 256 / L;
-    constexpr int U = 4;
+    constexpr int U = C <= 4 ? 8 : 4;   // records in flight per team
     const int lane = threadIdx.x % L;
     const int n_valid = n_valid_p[0];
     const long long chunk = (long long)blockIdx.x * TEAMS + threadIdx.x / L;
