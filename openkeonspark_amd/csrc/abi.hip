@@ -72,9 +72,11 @@ int ensure_device_index() {
     }
     if (e.dev.streams_sync == 0) {
         if (e.dev.streams_cap < e.work_threads) {
-            if (e.dev.streams) (void)hipFree(e.dev.streams);
-            e.dev.streams = nullptr;
-            if ((rc = hip_check(hipMalloc(&e.dev.streams, sizeof(uint64_t) * (size_t)e.work_threads), "alloc streams"))) return rc;
+            uint64_t *base = e.dev.streams < e.dev.streams_next ? e.dev.streams : e.dev.streams_next;   // one allocation, two halves
+            if (base) (void)hipFree(base);
+            e.dev.streams = e.dev.streams_next = nullptr;
+            if ((rc = hip_check(hipMalloc(&e.dev.streams, sizeof(uint64_t) * 2 * (size_t)e.work_threads), "alloc streams"))) return rc;
+            e.dev.streams_next = e.dev.streams + e.work_threads;
             e.dev.streams_cap = e.work_threads;
         }
         if ((rc = hip_check(hipMemcpy(e.dev.streams, e.streams.data(), sizeof(uint64_t) * (size_t)e.work_threads,

@@ -24,7 +24,8 @@ struct DeviceIndex {
     int2 *ht = nullptr;       // [train_dup]
     int32_t *tails_hr = nullptr, *heads_tr = nullptr, *rels_ht = nullptr;  // [train_uniq]
     float *bern_prob = nullptr;                                            // [rel_total]
-    uint64_t *streams = nullptr;                                           // [work_threads]
+    uint64_t *streams = nullptr;                                           // [work_threads]: the CURRENT states
+    uint64_t *streams_next = nullptr;   // the other half of the same allocation: the sampler writes the advanced states there, then the two swap
     int64_t streams_cap = 0;
     int streams_sync = 0;  // 0: host copy newer (upload before use), 1: in sync, 2: device copy newer
     // staging for the Base.so-compatible host-buffer `sampling`

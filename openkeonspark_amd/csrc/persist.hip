@@ -396,7 +396,7 @@ extern "C" int kge_train_steps_persistent(const kge_model_desc *m, float *const 
     SamplerArgs &s = pa.sm;
     s.pos = e.dev.pos; s.grp = e.dev.grp; s.ht = e.dev.ht;
     s.tails_hr = e.dev.tails_hr; s.heads_tr = e.dev.heads_tr; s.rels_ht = e.dev.rels_ht;
-    s.bern_prob = e.dev.bern_prob; s.streams = e.dev.streams;
+    s.bern_prob = e.dev.bern_prob; s.streams = e.dev.streams; s.streams_next = nullptr; s.W = W; s.B = B;
     s.out_h = g_batch; s.out_t = g_batch + batch_len; s.out_r = g_batch + 2 * batch_len;
     s.per_thread = (B % W == 0) ? B / W : B / W + 1; s.pos_lo = 0; s.n_local = B; s.out_stride = B;
     s.train_dup = e.index.train_dup; s.new_batch = e.index.new_batch;

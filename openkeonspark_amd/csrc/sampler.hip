@@ -17,6 +17,15 @@ __global__ __launch_bounds__(256) void sample_kernel(SamplerArgs a) {
     // relation negatives; padded to a power of two <= 64): they all read the same pos / grp record and search the same
     // groups, so those loads coalesce into one request instead of 1+neg requests from as many different blocks.
     const int kshift = a.kshift, kp = 1 + a.neg + a.negrel;
+    // After a batch every stream has moved by (slice length) * (draws per positive).  The advanced states go to the
+    // OTHER half of the double buffer (this launch reads only the current half, so no ordering between blocks is
+    // needed and no separate launch either); the host swaps the halves.
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < a.W; id += (long long)gridDim.x * blockDim.x) {
+        long long lef = id * a.per_thread, rig = lef + a.per_thread;
+        if (rig > a.B) rig = a.B;
+        if (lef > a.B) lef = a.B;
+        a.streams_next[id] = lcg_skip(a.streams[id], (unsigned long long)(rig - lef) * (unsigned long long)(kp + a.neg));
+    }
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; (g >> kshift) < a.n_local; g += (long long)gridDim.x * blockDim.x) {
         const long long b = g >> kshift;
         const long long k = g & ((1 << kshift) - 1);
@@ -28,7 +37,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SamplerArgs a) {
     }
 }
 
-// After a batch every stream has moved by (slice length) * (draws per positive).
+// The same advance in place, for a launch whose own slice is empty (a data-parallel rank without positions).
 __global__ void advance_streams_kernel(uint64_t *streams, long long W, long long B, long long per_thread,
                                        unsigned long long draws) {
     long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,11 +94,13 @@ int launch_sampler(int32_t *d_h, int32_t *d_t, int32_t *d_r, int64_t B, int64_t 
         a.kshift = kshift;
         int64_t blocks = ((n_local << kshift) + 255) / 256;
         if (blocks > (1 << 20)) blocks = 1 << 20;
+        a.streams_next = e.dev.streams_next; a.W = W; a.B = B;
         hipLaunchKernelGGL(sample_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-    }
-    hipLaunchKernelGGL(advance_streams_kernel, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, stream, e.dev.streams,
-                       (long long)W, (long long)B, (long long)per_thread,
-                       (unsigned long long)(1 + 2 * neg + negrel));
+        std::swap(e.dev.streams, e.dev.streams_next);
+    } else
+        hipLaunchKernelGGL(advance_streams_kernel, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, stream, e.dev.streams,
+                           (long long)W, (long long)B, (long long)per_thread,
+                           (unsigned long long)(1 + 2 * neg + negrel));
     e.dev.streams_sync = 2;  // device copy is now the newer one
     return hip_check(hipGetLastError(), "sampler launch");
 }

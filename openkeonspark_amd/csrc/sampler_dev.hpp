@@ -23,6 +23,8 @@ struct SamplerArgs {
     const int32_t *tails_hr, *heads_tr, *rels_ht;
     const float *bern_prob;
     const uint64_t *streams;
+    uint64_t *streams_next;   // sample_kernel: every stream's state after this batch (null: not written)
+    long long W, B;           // virtual threads, global batch (for streams_next)
     int32_t *out_h, *out_t, *out_r;
     long long per_thread;  // positions per virtual thread: B/W, or B/W+1 when W does not divide B
     long long pos_lo;      // first global batch position written by this launch

@@ -283,10 +283,15 @@ __global__ __launch_bounds__(256) void bkt_hist_kernel(const int32_t *__restrict
     for (int i = threadIdx.x; i <= NB; i += 256) hist[i] = 0;
     __syncthreads();
     const int base = blockIdx.x * BTILE;
-    for (int i = threadIdx.x; i < BTILE; i += 256) {
-        const int m = base + i;
-        if (m < M) atomicAdd(&hist[bucket_of(dst[m], rpb)], 1);
+    int d[BTILE / 256];
+#pragma unroll
+    for (int k = 0; k < BTILE / 256; k++) {   // all of the tile's loads in flight before the first LDS atomic
+        const int m = base + threadIdx.x + 256 * k;
+        d[k] = dst[m < M ? m : M - 1];
     }
+#pragma unroll
+    for (int k = 0; k < BTILE / 256; k++)
+        if (base + (int)threadIdx.x + 256 * k < M) atomicAdd(&hist[bucket_of(d[k], rpb)], 1);
     __syncthreads();
     for (int i = threadIdx.x; i <= NB; i += 256)
         if (hist[i]) atomicAdd(&bucket_total[i], hist[i]);
@@ -302,6 +307,13 @@ __global__ __launch_bounds__(256) void bkt_scatter_kernel(const int32_t *__restr
     __shared__ int hist[NB + 1];
     __shared__ int base_of[NB + 1];
     __shared__ int scan[1024];
+    const int base = blockIdx.x * BTILE;
+    int d[BTILE / 256];
+#pragma unroll
+    for (int k = 0; k < BTILE / 256; k++) {   // the tile's destinations travel while the totals are scanned
+        const int m = base + threadIdx.x + 256 * k;
+        d[k] = m < M ? dst[m] : -2;
+    }
     for (int i = threadIdx.x; i < 1024; i += 256) scan[i] = i <= NB ? bucket_total[i] : 0;
     for (int i = threadIdx.x; i <= NB; i += 256) hist[i] = 0;
     __syncthreads();
@@ -318,14 +330,9 @@ __global__ __launch_bounds__(256) void bkt_scatter_kernel(const int32_t *__restr
     if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i <= NB + 1; i += 256) bucket_start[i] = i ? scan[i - 1] : 0;
     }
-    const int base = blockIdx.x * BTILE;
-    int d[BTILE / 256];
 #pragma unroll
-    for (int k = 0; k < BTILE / 256; k++) {
-        const int m = base + threadIdx.x + 256 * k;
-        d[k] = m < M ? dst[m] : -2;
-        if (m < M) atomicAdd(&hist[bucket_of(d[k], rpb)], 1);
-    }
+    for (int k = 0; k < BTILE / 256; k++)
+        if (base + (int)threadIdx.x + 256 * k < M) atomicAdd(&hist[bucket_of(d[k], rpb)], 1);
     __syncthreads();
     for (int i = threadIdx.x; i <= NB; i += 256) {
         const int c = hist[i];
@@ -362,8 +369,17 @@ __global__ __launch_bounds__(256) void bkt_sort_kernel(const int2 *__restrict__ 
     if (row0 >= rows) return;
     const int start = bucket_start[b], end = bucket_start[b + 1];
     for (int i = threadIdx.x; i < rpb; i += 256) lds_h[i] = 0;
+    if (end == start) return;
+    // the first 256*PC pairs of the bucket (all of it, normally) are read ONCE, into registers, for both passes
+    constexpr int PC = 8;
+    int2 pr[PC];
+#pragma unroll
+    for (int k = 0; k < PC; k++) pr[k] = pairs[min(start + (int)threadIdx.x + 256 * k, end - 1)];
     __syncthreads();
-    for (int i = start + threadIdx.x; i < end; i += 256) atomicAdd(&lds_h[pairs[i].y - row0], 1);
+#pragma unroll
+    for (int k = 0; k < PC; k++)
+        if (start + (int)threadIdx.x + 256 * k < end) atomicAdd(&lds_h[pr[k].y - row0], 1);
+    for (int i = start + 256 * PC + threadIdx.x; i < end; i += 256) atomicAdd(&lds_h[pairs[i].y - row0], 1);
     __syncthreads();
     if (threadIdx.x < 64) {   // exclusive scan of rpb counters by one wave
         int carry = 0;
@@ -378,11 +394,18 @@ __global__ __launch_bounds__(256) void bkt_sort_kernel(const int2 *__restrict__ 
         }
     }
     __syncthreads();
-    for (int i = start + threadIdx.x; i < end; i += 256) {
-        const int2 pr = pairs[i];
-        const int pos = start + atomicAdd(&lds_h[pr.y - row0], 1);
-        out_keys[pos] = pr.y;
-        out_ids[pos] = pr.x;
+#pragma unroll
+    for (int k = 0; k < PC; k++)
+        if (start + (int)threadIdx.x + 256 * k < end) {
+            const int pos = start + atomicAdd(&lds_h[pr[k].y - row0], 1);
+            out_keys[pos] = pr[k].y;
+            out_ids[pos] = pr[k].x;
+        }
+    for (int i = start + 256 * PC + threadIdx.x; i < end; i += 256) {
+        const int2 q = pairs[i];
+        const int pos = start + atomicAdd(&lds_h[q.y - row0], 1);
+        out_keys[pos] = q.y;
+        out_ids[pos] = q.x;
     }
 }
 
