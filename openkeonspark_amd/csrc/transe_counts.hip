@@ -109,6 +109,23 @@ __global__ void count_valid_kernel(const int32_t *__restrict__ sorted, int M, in
 
 constexpr int CHUNK = 64;
 
+// value held by lane `i` of the calling lane's L-lane team (i a compile-time constant where it matters: a full wave reads it
+// into an SGPR with v_readlane, narrower teams go through ds_bpermute)
+template <int L>
+__device__ __forceinline__ int team_pick(int v, int i) {
+    if constexpr (L == 64) return __builtin_amdgcn_readlane(v, i);
+    else return __shfl(v, i, L);
+}
+// entry i of a CHUNK-long list held as a[j] = entry (lane + L*j); never indexes `a` dynamically (an unrolled select), so the
+// array stays in registers even where the caller's loop is not unrolled
+template <int L, int J>
+__device__ __forceinline__ int chunk_entry(const int (&a)[J], int i) {
+    int v = a[0];
+#pragma unroll
+    for (int j = 1; j < J; j++) v = (i / L == j) ? a[j] : v;
+    return team_pick<L>(v, i % L);
+}
+
 // element held in accumulator c of `lane`: strided layout (dword-per-lane kernels) or natural layout
 // (vectorised kernels: record dword w = lane + L*(c/4) holds elements 4w .. 4w+3)
 template <int L, bool NAT>
@@ -218,15 +235,28 @@ __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict_
     int cur_row = uidx ? uidx[start] : cur;
     bool first_run = true;
     constexpr int U = 16;  // records in flight per team
-    for (int i0 = 0; i0 < n; i0 += U) {
+    // the chunk's keys / record ids / unique-row indices: ONE coalesced load each (lane l holds entries l, l+L, ...),
+    // handed to the team record by record with a lane broadcast -- not one dependent scalar load per group of U
+    constexpr int J = CHUNK / L;
+    int kl[J], idl[J], url[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int i = min(lane + L * j, n - 1);
+        kl[j] = keys[start + i];
+        idl[j] = ids[start + i];
+        url[j] = uidx ? uidx[start + i] : kl[j];
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < CHUNK; i0 += U) {
+        if (i0 >= n) break;
         int k[U], id[U], ur[U];
         uint32_t w[U][Q];
 #pragma unroll
-        for (int u = 0; u < U; u++) {   // unconditional (clamped) loads: all in flight together
-            const int i = min(i0 + u, n - 1);
-            k[u] = keys[start + i];
-            id[u] = ids[start + i];
-            ur[u] = uidx ? uidx[start + i] : k[u];
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u;   // compile-time after unrolling; entries past n hold the clamped last record
+            k[u] = chunk_entry<L, J>(kl, i);
+            id[u] = chunk_entry<L, J>(idl, i);
+            ur[u] = chunk_entry<L, J>(url, i);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -500,14 +530,25 @@ __global__ __launch_bounds__(256) void segsum_f32_kernel(const float *__restrict
     for (int c = 0; c < C; c++) acc[c] = 0.f;
     int cur = keys[start];
     bool first_run = true;
-    for (int i0 = 0; i0 < n; i0 += U) {
+    // the chunk's keys and record ids in one coalesced load each (chunk_len <= CHUNK), broadcast per record (see segsum_kernel)
+    constexpr int J = CHUNK / L;
+    int kl[J], idl[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int i = min(lane + L * j, n - 1);
+        kl[j] = keys[start + i];
+        idl[j] = ids[start + i];
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < CHUNK; i0 += U) {
+        if (i0 >= n) break;
         int k[U];
         float x[U][C];
 #pragma unroll
-        for (int u = 0; u < U; u++) {   // unconditional (clamped) loads: all in flight together
-            const int i = min(i0 + u, n - 1);
-            k[u] = keys[start + i];
-            const float *p = rec + (long long)ids[start + i] * D;
+        for (int u = 0; u < U; u++) {   // unconditional loads (entries past n repeat the last record): all in flight together
+            const int i = i0 + u;
+            k[u] = chunk_entry<L, J>(kl, i);
+            const float *p = rec + (long long)chunk_entry<L, J>(idl, i) * D;
 #pragma unroll
             for (int c = 0; c < C; c++) { const int e = lane + L * c; x[u][c] = p[e < D ? e : 0]; }
         }
