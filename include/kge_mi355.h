@@ -115,6 +115,11 @@ const char *kge_version(void);
  *   "float_records":     1 (default) = kge_forward_backward stores TransE/H/D gradient rows as records and sums
  *                        them by destination after a sort; 0 = fp32 atomic adds straight into the accumulators
  *   "float_records_min": smallest number of gradient rows per step that takes the record path (default 65536: measured cross-over, tools/sweep_paths.py)
+ *   "pair_counts":       1 (default) = TransH / TransD steps of at least float_records_min entity-side rows (widths that are
+ *                        multiples of 4 up to 256, at most 63 negatives, ent_total*rel_total sortable by the counting sort) take the
+ *                        pair-count path: int8 sign records keyed by (entity, relation), the backward applied once per pair
+ *                        (csrc/pairs.hip); 0 = float records / atomics as for the other shapes
+ *   "pair_counts_min_neg": fewest negatives per positive for that path (default 4)
  *   "index_device_min":  training sets with at least this many lines are indexed on the device (rocPRIM sorts,
  *                        same arrays bit for bit); default 4194304, 0 = always, negative = never
  *   "hub_copies":        1 (default) = on the fp32-atomic TransH/TransD path, relation-side gradient rows that would

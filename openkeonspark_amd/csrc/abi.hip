@@ -224,6 +224,8 @@ int kge_set_option(const char *name, INT value) {
     if (n == "float_records_min") { engine().float_records_min = value; return KGE_OK; }
     if (n == "index_device_min") { engine().index_device_min = value; return KGE_OK; }
     if (n == "hub_copies") { engine().hub_copies = value != 0; return KGE_OK; }
+    if (n == "pair_counts") { engine().pair_counts = value != 0; return KGE_OK; }
+    if (n == "pair_counts_min_neg") { engine().pair_counts_min_neg = (int)value; return KGE_OK; }
     if (n == "lp_v1") { engine().lp_v1 = value != 0; return KGE_OK; }
     if (n == "transr_v1") { engine().transr_v1 = (int)value; return KGE_OK; }
     if (n == "time_emit") { engine().time_emit = value > 0 ? (int)value : 0; if (value > 0) { engine().emit_launches = 0; engine().emit_seen = 0; } return KGE_OK; }

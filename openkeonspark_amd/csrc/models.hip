@@ -244,19 +244,6 @@ __global__ __launch_bounds__(256) void transe_emit_kernel(FbArgs a) {
 //   * the integer gradient vectors are packed int16 pairs (v_pk_add_i16), bytes only when stored;
 //   * one global_load_dwordx4 per row chunk.  Record dword w = lane + L*q holds elements 4w..4w+3
 //     ("natural" layout, flagged to the reducers).
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ int sign_of_bits(float e) {
-    int r;
-    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(__builtin_bit_cast(int, e)));
-    return r;
-}
-__device__ __forceinline__ s16x2 pack16(int lo, int hi) { s16x2 r; r.x = (short)lo; r.y = (short)hi; return r; }
-// the four low bytes of two int16 pairs -> one record dword
-__device__ __forceinline__ uint32_t bytes_of(s16x2 lo, s16x2 hi) {
-    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
-}
-
 template <int L, int Q, int K, int WPE, bool INV_TAB, bool BF16 = false>
 __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
     constexpr int TEAMS = 256 / L;
@@ -723,6 +710,60 @@ static int dispatch_fb(const FbArgs &a, float *d_loss, hipStream_t stream) {
     return KGE_OK;
 }
 
+// Atomic relation-side adds on a KG with few relations: group b adds into copy b % hub_k of [hub_k][R][D] buffers (zero between
+// steps: hub_fold_kernel re-zeroes what it folds) when a relation-side row would take >= 128 adds per step.
+static int attach_hub_copies(const kge_model_desc &m, int64_t n_pos, FbArgs &a) {
+    Engine &e = engine();
+    const int64_t hub_rows = (m.model == KGE_TRANSE ? 1 : 2) * m.rel_total;
+    const int64_t group_rel = m.model == KGE_TRANSE ? 1 : 2;
+    const int64_t per_row = hub_rows > 0 ? (group_rel * n_pos) / hub_rows : 0;
+    if (m.model == KGE_TRANSE || per_row < 128 || !e.hub_copies) return KGE_OK;
+    int64_t copies = per_row / 16;
+    if (copies > 64) copies = 64;
+    const int64_t per_copy = m.rel_total * (int64_t)a.D;
+    while (copies > 1 && copies * per_copy * 4 > (int64_t(32) << 20)) copies >>= 1;
+    if (copies <= 1) return KGE_OK;
+    static float *buf_rel = nullptr, *buf_auxr = nullptr;
+    static int64_t buf_elems = 0;
+    int rc;
+    if (copies * per_copy > buf_elems) {
+        if (buf_rel) (void)hipFree(buf_rel);
+        if (buf_auxr) (void)hipFree(buf_auxr);
+        buf_rel = buf_auxr = nullptr;
+        buf_elems = copies * per_copy;
+        if ((rc = hip_check(hipMalloc(&buf_rel, sizeof(float) * (size_t)buf_elems), "alloc hub copies"))) return rc;
+        if ((rc = hip_check(hipMalloc(&buf_auxr, sizeof(float) * (size_t)buf_elems), "alloc hub copies"))) return rc;
+        if ((rc = hip_check(hipMemset(buf_rel, 0, sizeof(float) * (size_t)buf_elems), "zero hub copies"))) return rc;
+        if ((rc = hip_check(hipMemset(buf_auxr, 0, sizeof(float) * (size_t)buf_elems), "zero hub copies"))) return rc;
+    }
+    a.copies_rel = buf_rel; a.copies_auxr = buf_auxr; a.hub_k = (int)copies;
+    a.rel_total = (int)m.rel_total;
+    return KGE_OK;
+}
+
+// pair-count path (pairs.hip, transe_counts.hip)
+bool pair_counts_shape_ok(int model, int D, int64_t n_neg);
+bool pair_keys_sortable(int64_t ent_total, int64_t rel_total);
+long long pair_emit_blocks(int64_t n_pos);
+int pair_record_dwords(int D);
+void launch_pair_emit(int model, const FbArgs &a, hipStream_t stream);
+int pair_records_workspace(int64_t M, int rd, uint32_t *&rec, int32_t *&dst);
+int pair_records_reduce(int model, int64_t M, int D, int rd, int64_t ent_total, int64_t rel_total, const float *const tables[4],
+                        float *const grads[4], float unit, hipStream_t stream);
+
+// the exact fp32 kernel over the groups an emit kernel deferred (a.group_list), partial losses behind the emit kernel's
+template <int MODEL>
+static int dispatch_fb_deferred(const FbArgs &a, hipStream_t stream) {
+    const int D = a.D;
+#define KGE_DEFER(LL, CC) hipLaunchKernelGGL((fwdbwd_kernel<MODEL, LL, CC>), dim3(kDeferBlocks), dim3(256), 0, stream, a)
+    if (D <= 16) KGE_DEFER(16, 1); else if (D <= 32) KGE_DEFER(16, 2); else if (D <= 64) KGE_DEFER(16, 4);
+    else if (D <= 128) KGE_DEFER(32, 4); else if (D <= 256) KGE_DEFER(64, 4); else if (D <= 512) KGE_DEFER(64, 8);
+    else if (D <= 1024) KGE_DEFER(64, 16);
+    else return fail(KGE_ERR_UNSUPPORTED, "embedding dimension > 1024 is not supported by the vector-model kernels");
+#undef KGE_DEFER
+    return KGE_OK;
+}
+
 // TransR: the score / hinge / backward over the projected vectors (transr.hip runs the GEMMs around it)
 int launch_transr_vector_stage(const float *rel, float *g_rel, const float *P, float *GP, const int32_t *d_h,
                                const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
@@ -764,6 +805,42 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
     a.loss_partials = e.dev.loss_partials;
     a.P = nullptr; a.GP = nullptr; a.negative_rel = m.negative_rel;
     int rc;
+    // Pair-count path (TransH / TransD): int8 sign records keyed by (entity, relation), the backward applied once per pair
+    if (e.pair_counts && n_neg >= e.pair_counts_min_neg && pair_counts_shape_ok(m.model, a.D, n_neg) && pair_keys_sortable(m.ent_total, m.rel_total) &&
+        n_pos * (2 + n_neg) >= e.float_records_min && n_pos * (2 + n_neg) < (int64_t(1) << 31)) {
+        const int64_t M = n_pos * (2 + n_neg);
+        const int rd = pair_record_dwords(a.D);
+        if ((rc = pair_records_workspace(M, rd, a.rec, a.dst))) return rc;
+        if (n_pos > g_defer_cap) {
+            if (g_defer_list) (void)hipFree(g_defer_list);
+            g_defer_list = nullptr;
+            if ((rc = hip_check(hipMalloc(&g_defer_list, sizeof(int32_t) * (size_t)n_pos), "alloc deferred groups"))) return rc;
+            if (!g_defer_count && (rc = hip_check(hipMalloc(&g_defer_count, sizeof(int32_t)), "alloc deferred count"))) return rc;
+            g_defer_cap = n_pos;
+        }
+        if ((rc = hip_check(hipMemsetAsync(g_defer_count, 0, sizeof(int32_t), stream), "zero deferred count"))) return rc;
+        a.group_list = g_defer_list; a.group_count = g_defer_count;
+        a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total;
+        if ((rc = attach_hub_copies(m, n_pos, a))) return rc;
+        guard_loss_stream(stream);
+        launch_pair_emit(m.model, a, stream);
+        // groups with negatives that are not sampler-shaped: the exact fp32 kernel (atomic adds), its partial losses behind the emit's
+        FbArgs d = a;
+        d.loss_partials = a.loss_partials + pair_emit_blocks(n_pos);
+        rc = m.model == KGE_TRANSH ? dispatch_fb_deferred<KGE_TRANSH>(d, stream) : dispatch_fb_deferred<KGE_TRANSD>(d, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, a.loss_partials, (int)pair_emit_blocks(n_pos) + kDeferBlocks,
+                           a.unit, d_loss);
+        if ((rc = pair_records_reduce(m.model, M, a.D, rd, m.ent_total, m.rel_total, tables, grads, a.unit, stream))) return rc;
+        if (a.copies_rel) {
+            const long long RD = (long long)m.rel_total * a.D;
+            long long nb = (2 * RD + 255) / 256;
+            if (nb > 1024) nb = 1024;
+            hipLaunchKernelGGL(hub_fold_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.copies_rel, a.copies_auxr, grads[1], grads[2],
+                               a.hub_k, RD);
+        }
+        return hip_check(hipGetLastError(), "pair-count forward_backward launch");
+    }
     // Float-record path: gradient rows are stored as records, ordered by destination row and summed by
     // segments into the accumulators (plain stores + one sorted pass instead of memory-side fp32 atomics,
     // which cap at ~1.1 TB/s).  Worth it once a step has enough rows to fill the chip.
@@ -800,30 +877,7 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
         return float_records_reduce(M, a.D, rs, stream);
     }
     // atomic path: hub copies for the relation-side rows when a row would take hundreds of adds per step
-    const int64_t per_row = hub_rows > 0 ? (group_rel * n_pos) / hub_rows : 0;
-    int64_t copies = 0;
-    if (m.model != KGE_TRANSE && per_row >= 128 && e.hub_copies) {
-        copies = per_row / 16;
-        if (copies > 64) copies = 64;
-        const int64_t per_copy = m.rel_total * (int64_t)a.D;
-        while (copies > 1 && copies * per_copy * 4 > (int64_t(32) << 20)) copies >>= 1;
-        if (copies > 1) {
-            static float *buf_rel = nullptr, *buf_auxr = nullptr;
-            static int64_t buf_elems = 0;
-            if (copies * per_copy > buf_elems) {
-                if (buf_rel) (void)hipFree(buf_rel);
-                if (buf_auxr) (void)hipFree(buf_auxr);
-                buf_rel = buf_auxr = nullptr;
-                buf_elems = copies * per_copy;
-                if ((rc = hip_check(hipMalloc(&buf_rel, sizeof(float) * (size_t)buf_elems), "alloc hub copies"))) return rc;
-                if ((rc = hip_check(hipMalloc(&buf_auxr, sizeof(float) * (size_t)buf_elems), "alloc hub copies"))) return rc;
-                if ((rc = hip_check(hipMemset(buf_rel, 0, sizeof(float) * (size_t)buf_elems), "zero hub copies"))) return rc;
-                if ((rc = hip_check(hipMemset(buf_auxr, 0, sizeof(float) * (size_t)buf_elems), "zero hub copies"))) return rc;
-            }
-            a.copies_rel = buf_rel; a.copies_auxr = buf_auxr; a.hub_k = (int)copies;
-            a.rel_total = (int)m.rel_total;
-        }
-    }
+    if ((rc = attach_hub_copies(m, n_pos, a))) return rc;
     switch (m.model) {
         case KGE_TRANSE: rc = dispatch_fb<KGE_TRANSE>(a, d_loss, stream); break;
         case KGE_TRANSH: rc = dispatch_fb<KGE_TRANSH>(a, d_loss, stream); break;

@@ -121,6 +121,20 @@ __device__ __forceinline__ void put_row(const Team<L, C> &tm, const FbArgs &a, f
     }
 }
 
+// ---- integer sign vectors (sign-count paths: TransE emit in models.hip, pair-count emit in pairs.hip) ----
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int sign_of_bits(float e) {
+    int r;
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(__builtin_bit_cast(int, e)));
+    return r;
+}
+__device__ __forceinline__ s16x2 pack16(int lo, int hi) { s16x2 r; r.x = (short)lo; r.y = (short)hi; return r; }
+// the four low bytes of two int16 pairs -> one record dword
+__device__ __forceinline__ uint32_t bytes_of(s16x2 lo, s16x2 hi) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
+}
+
 // One entity side (h or t slot) of a scored triple: raw row(s), projected+normalised vector.
 template <int C>
 struct Side {

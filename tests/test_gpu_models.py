@@ -132,19 +132,25 @@ def test_transr_forward_backward_matches_oracle(E, R, De, Dr, n, nr, foreign, tr
         assert relerr(g_g[k], g_o[k]) < RTOL, (k, relerr(g_g[k], g_o[k]))
 
 
-@pytest.fixture(params=["atomic", "records-bucket", "records-sort"])
+@pytest.fixture(params=["atomic", "records-bucket", "records-sort", "pairs"])
 def grad_path(request):
-    """The three accumulations of the fp32 gradient rows: memory-side atomics, or float records ordered by the
-    two-level counting sort / by rocPRIM's radix sort and summed by segments (the default on large steps)."""
+    """The accumulations of the gradient rows: memory-side fp32 atomics; float records ordered by the two-level counting
+    sort / by rocPRIM's radix sort and summed by segments; and, for TransH / TransD at widths that are multiples of 4 up to
+    256, int8 sign records keyed by (entity, relation) with the backward applied once per pair (the default on large steps;
+    other models and widths fall through to the float records)."""
     from openkeonspark_amd import _lib
     L = _lib.lib()
     L.kge_set_option(b"float_records", 0 if request.param == "atomic" else 1)
     L.kge_set_option(b"float_records_min", 0)
     L.kge_set_option(b"counts_force_sort", 1 if request.param == "records-sort" else 0)
+    L.kge_set_option(b"pair_counts", 1 if request.param == "pairs" else 0)
+    L.kge_set_option(b"pair_counts_min_neg", 1)
     yield request.param
     L.kge_set_option(b"float_records", 1)
     L.kge_set_option(b"float_records_min", 1 << 16)
     L.kge_set_option(b"counts_force_sort", 0)
+    L.kge_set_option(b"pair_counts", 1)
+    L.kge_set_option(b"pair_counts_min_neg", 4)
 
 
 @pytest.mark.parametrize("model,E,R,D", CASES)
