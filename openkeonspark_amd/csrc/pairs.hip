@@ -36,15 +36,18 @@ struct Rows {   // a row as this lane sees it: Q float4 chunks
     float v[4 * Q];
 };
 
+// Row gather in the natural layout.  Q = ceil(D / 64), so every lane's chunks q < Q-1 exist; only the last chunk can lie
+// past the row's end.  It is loaded from a clamped address and zeroed by a select: a conditional load would compile into a
+// branch around it with its own wait, i.e. one memory latency per chunk instead of one per row.
 template <int Q>
 __device__ __forceinline__ void load_row(const float *__restrict__ tab, long long row, int D, int lane, float (&x)[4 * Q]) {
     const float *p = tab + row * D;
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         const int e0 = 4 * (lane + PT * q);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e0 < D) v = *reinterpret_cast<const float4 *>(p + e0);
-        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        const bool ok = q < Q - 1 || e0 < D;
+        const float4 v = *reinterpret_cast<const float4 *>(p + (ok ? e0 : 0));
+        x[4 * q] = ok ? v.x : 0.f; x[4 * q + 1] = ok ? v.y : 0.f; x[4 * q + 2] = ok ? v.z : 0.f; x[4 * q + 3] = ok ? v.w : 0.f;
     }
 }
 

@@ -609,18 +609,34 @@ __global__ __launch_bounds__(256) void segsum_f32_kernel(const float *__restrict
 // One wave per chunk of 64 sorted records, lane l holding elements 4l..4l+3 (D <= 256).
 // ---------------------------------------------------------------------------------------------
 struct PairRed {
-    const float *ent, *auxr, *auxe;   // ent_embeddings, normal_vectors | rel_transfer, ent_transfer (TransD)
+    const float *ent, *ctx, *auxe;    // ent_embeddings; per relation: TransH the NORMALISED normal vector (ctx_normalize_kernel), TransD rel_transfer; ent_transfer (TransD)
     float *g_ent, *g_auxe;
     int D, R, RD;                     // embedding width, relations, dwords per record
+    unsigned magic;                   // ceil(2^32 / R): key / R by multiply-high (+ fix-up)
     float unit;
 };
 
 __device__ __forceinline__ float dot4(const float4 &a, const float4 &b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
+// l2_normalize of every normal vector, once per step (TransH): the per-pair backward then needs no norm of w
+__global__ __launch_bounds__(256) void ctx_normalize_kernel(const float *__restrict__ w, int R, int D, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += gridDim.x * 4) {
+        float ss = 0.f;
+        for (int e = lane; e < D; e += 64) ss += w[(long long)r * D + e] * w[(long long)r * D + e];
+        ss = team_sum<64>(ss);
+        const float inv = 1.0f / sqrtf(ss >= 1e-12f ? ss : 1e-12f);
+        for (int e = lane; e < D; e += 64) out[(long long)r * D + e] = w[(long long)r * D + e] * inv;
+    }
+}
+
 template <int MODEL>
 __global__ __launch_bounds__(256) void segsum_pairs_kernel(const uint32_t *__restrict__ rec, const int32_t *__restrict__ keys,
                                                            const int32_t *__restrict__ ids, const int32_t *__restrict__ n_valid_p, PairRed pr) {
     constexpr int L = 64;
+    constexpr int W = 4;   // records of a pair requested together with its rows (longer runs: a follow-up loop)
+    __shared__ float stage_all[4][256];   // atomic flushes go out in the strided layout (see flush_run): one turn-around buffer per wave
+    float *stage = stage_all[threadIdx.x / L];
     const int lane = threadIdx.x % L;
     const int n_valid = n_valid_p[0];
     const long long chunk = (long long)blockIdx.x * (256 / L) + threadIdx.x / L;
@@ -629,72 +645,28 @@ __global__ __launch_bounds__(256) void segsum_pairs_kernel(const uint32_t *__res
     const int n = (int)min((long long)CHUNK, n_valid - start);
     const bool valid = 4 * lane < pr.D;
     const int D = pr.D, R = pr.R;
-    int acc[4] = {0, 0, 0, 0};
+    const int lane4 = valid ? 4 * lane : 0;   // clamped element offset: loads stay unconditional, invalid lanes are zeroed by selects
+    const int kl = keys[start + min(lane, n - 1)], idl = ids[start + min(lane, n - 1)];
+    // the runs (pairs) of this chunk are known up front: bit i of `starts` = record i opens a run
+    const int prev = __shfl_up(kl, 1);
+    unsigned long long starts = __ballot(lane < n && (lane == 0 || kl != prev));
     float4 racc = make_float4(0.f, 0.f, 0.f, 0.f), racc2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    int kl[1], idl[1];
-    {
-        const int i = min(lane, n - 1);
-        kl[0] = keys[start + i];
-        idl[0] = ids[start + i];
-    }
-    int cur = __builtin_amdgcn_readlane(kl[0], 0);
-    int cur_row = cur / R;
+    int cur_row = -1;
     bool first_row = true;
-    // the entity-row gradient of pair `cur` from its integer sign sum (side_backward of models_dev.hpp, applied once per pair)
-    auto pair_apply = [&]() {
-        const int rel = cur - cur_row * R;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 x = valid ? *reinterpret_cast<const float4 *>(pr.ent + (long long)cur_row * D + 4 * lane) : z;
-        float4 cw = valid ? *reinterpret_cast<const float4 *>(pr.auxr + (long long)rel * D + 4 * lane) : z;
-        float4 xa = z, xp;
-        float a;
-        if constexpr (MODEL == KGE_TRANSH) {
-            const float ssw = team_sum<L>(dot4(cw, cw));
-            const float iw = 1.0f / sqrtf(ssw >= 1e-12f ? ssw : 1e-12f);
-            cw = make_float4(cw.x * iw, cw.y * iw, cw.z * iw, cw.w * iw);
-            a = team_sum<L>(dot4(x, cw));
-            xp = make_float4(x.x - a * cw.x, x.y - a * cw.y, x.z - a * cw.z, x.w - a * cw.w);
-        } else {
-            xa = valid ? *reinterpret_cast<const float4 *>(pr.auxe + (long long)cur_row * D + 4 * lane) : z;
-            a = team_sum<L>(dot4(x, xa));
-            xp = make_float4(x.x + a * cw.x, x.y + a * cw.y, x.z + a * cw.z, x.w + a * cw.w);
-        }
-        const float ss = team_sum<L>(dot4(xp, xp));
-        const bool uc = ss >= 1e-12f;
-        const float inv = 1.0f / sqrtf(uc ? ss : 1e-12f);
-        const float4 nrm = make_float4(xp.x * inv, xp.y * inv, xp.z * inv, xp.w * inv);
-        const float4 G = make_float4(pr.unit * (float)acc[0], pr.unit * (float)acc[1], pr.unit * (float)acc[2], pr.unit * (float)acc[3]);
-        float dd = team_sum<L>(dot4(nrm, G));
-        if (!uc) dd = 0.f;
-        const float4 gxp = make_float4(inv * (G.x - dd * nrm.x), inv * (G.y - dd * nrm.y), inv * (G.z - dd * nrm.z), inv * (G.w - dd * nrm.w));
-        const float d = team_sum<L>(dot4(gxp, cw));
-        if constexpr (MODEL == KGE_TRANSH) {
-            racc.x += gxp.x - d * cw.x; racc.y += gxp.y - d * cw.y; racc.z += gxp.z - d * cw.z; racc.w += gxp.w - d * cw.w;
-        } else {
-            racc.x += gxp.x + d * xa.x; racc.y += gxp.y + d * xa.y; racc.z += gxp.z + d * xa.z; racc.w += gxp.w + d * xa.w;
-            racc2.x += d * x.x; racc2.y += d * x.y; racc2.z += d * x.z; racc2.w += d * x.w;
-        }
-    };
-    __shared__ float stage_all[4][256];   // atomic flushes go out in the strided layout (see flush_run): one turn-around buffer per wave
-    float *stage = stage_all[threadIdx.x / L];
     auto flush_one = [&](float *tab, const float4 &v, bool atomic) {
-        float *p = tab + (long long)cur_row * D + 4 * lane;
+        float *pr_ = tab + (long long)cur_row * D;
         if (atomic) {
             *reinterpret_cast<float4 *>(stage + 4 * lane) = v;
-            float *pr = tab + (long long)cur_row * D;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int e = lane + L * c;
                 const float x = stage[e];
-                if (e < D) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(pr + e), x);
+                if (e < D) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(pr_ + e), x);
             }
-            return;
-        }
-        if (!valid) return;
-        {
-            float4 o = *reinterpret_cast<float4 *>(p);
+        } else if (valid) {
+            float4 o = *reinterpret_cast<float4 *>(pr_ + 4 * lane);
             o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-            *reinterpret_cast<float4 *>(p) = o;
+            *reinterpret_cast<float4 *>(pr_ + 4 * lane) = o;
         }
     };
     auto flush_row = [&](bool atomic) {
@@ -702,34 +674,85 @@ __global__ __launch_bounds__(256) void segsum_pairs_kernel(const uint32_t *__res
         if constexpr (MODEL == KGE_TRANSD) flush_one(pr.g_auxe, racc2, atomic);
         racc = make_float4(0.f, 0.f, 0.f, 0.f); racc2 = make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    constexpr int U = 16;
+    // one pair = one run of equal keys: [lo, hi) inside the chunk.  Its rows and first W records are REQUESTED one pair ahead
+    // of the arithmetic (the dependent gathers, not the arithmetic, bounded the first version of this kernel).
+    struct Pair { int lo, hi, row, rel; float4 x, cw, xa; uint32_t w[W]; };
+    auto request = [&](Pair &q, int lo, int hi) {
+        q.lo = lo; q.hi = hi;
+        const unsigned key = (unsigned)__builtin_amdgcn_readlane(kl, lo);
+        int row = (int)__umulhi(key, pr.magic), rel = (int)key - row * R;
+        if (rel < 0) { row--; rel += R; }
+        if (rel >= R) { row++; rel -= R; }
+        q.row = row; q.rel = rel;
+        q.x = *reinterpret_cast<const float4 *>(pr.ent + (long long)row * D + lane4);
+        q.cw = *reinterpret_cast<const float4 *>(pr.ctx + (long long)rel * D + lane4);
+        if constexpr (MODEL == KGE_TRANSD) q.xa = *reinterpret_cast<const float4 *>(pr.auxe + (long long)row * D + lane4);
 #pragma unroll
-    for (int i0 = 0; i0 < CHUNK; i0 += U) {
-        if (i0 >= n) break;
-        int k[U];
-        uint32_t w[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {   // entries past n repeat the last record: loads stay unconditional
-            k[u] = chunk_entry<L, 1>(kl, i0 + u);
-            const long long id = chunk_entry<L, 1>(idl, i0 + u);
-            w[u] = valid ? rec[id * pr.RD + lane] : 0u;
+        for (int u = 0; u < W; u++) {
+            const long long id = __builtin_amdgcn_readlane(idl, min(lo + u, hi - 1));
+            q.w[u] = rec[id * pr.RD + (valid ? lane : 0)];
         }
+    };
+    auto next_run = [&](int &lo, int &hi) {
+        lo = __ffsll((long long)starts) - 1;
+        starts &= starts - 1;
+        hi = starts ? __ffsll((long long)starts) - 1 : n;
+    };
+    Pair cur;
+    { int lo, hi; next_run(lo, hi); request(cur, lo, hi); }
+    for (;;) {
+        const bool more = starts != 0;
+        Pair nxt;
+        if (more) { int lo, hi; next_run(lo, hi); request(nxt, lo, hi); }
+        // ---- integer sum of the run ----
+        int acc[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (i0 + u >= n) break;
-            if (k[u] != cur) {
-                pair_apply();
-                acc[0] = acc[1] = acc[2] = acc[3] = 0;
-                const int nrow = k[u] / R;
-                if (nrow != cur_row) { flush_row(first_row); first_row = false; }
-                cur = k[u];
-                cur_row = nrow;
-            }
+        for (int u = 0; u < W; u++) {
+            const uint32_t w = cur.lo + u < cur.hi ? cur.w[u] : 0u;
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[j] += (int)(int8_t)(w[u] >> (8 * j));
+            for (int j = 0; j < 4; j++) acc[j] += (int)(int8_t)(w >> (8 * j));
         }
+        for (int i = cur.lo + W; i < cur.hi; i++) {   // long runs (hub pairs): the rest, one record at a time
+            const long long id = __builtin_amdgcn_readlane(idl, i);
+            const uint32_t w = rec[id * pr.RD + (valid ? lane : 0)];
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[j] += (int)(int8_t)(w >> (8 * j));
+        }
+        if (cur.row != cur_row) {
+            if (cur_row >= 0) { flush_row(first_row); first_row = false; }
+            cur_row = cur.row;
+        }
+        // ---- the pair's entity-row gradient (side_backward of models_dev.hpp applied once to the summed signs) ----
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 x = valid ? cur.x : z, cw = valid ? cur.cw : z;
+        float4 xa = z, xp;
+        float a;
+        if constexpr (MODEL == KGE_TRANSH) {
+            a = team_sum<L>(dot4(x, cw));
+            xp = make_float4(x.x - a * cw.x, x.y - a * cw.y, x.z - a * cw.z, x.w - a * cw.w);
+        } else {
+            xa = valid ? cur.xa : z;
+            a = team_sum<L>(dot4(x, xa));
+            xp = make_float4(x.x + a * cw.x, x.y + a * cw.y, x.z + a * cw.z, x.w + a * cw.w);
+        }
+        const float4 S = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+        float ss = dot4(xp, xp), dp = dot4(xp, S);
+        ss = team_sum<L>(ss); dp = team_sum<L>(dp);
+        const bool uc = ss >= 1e-12f;
+        const float inv = 1.0f / sqrtf(uc ? ss : 1e-12f);
+        const float al = uc ? inv * pr.unit * dp : 0.f;       // <nrm, G>,  G = unit S
+        const float cg = inv * pr.unit, cx = -inv * inv * al;   // gxp = inv (G - al nrm) = cg S + cx xp
+        const float4 gxp = make_float4(cg * S.x + cx * xp.x, cg * S.y + cx * xp.y, cg * S.z + cx * xp.z, cg * S.w + cx * xp.w);
+        const float d = team_sum<L>(dot4(gxp, cw));
+        if constexpr (MODEL == KGE_TRANSH) {
+            racc.x += gxp.x - d * cw.x; racc.y += gxp.y - d * cw.y; racc.z += gxp.z - d * cw.z; racc.w += gxp.w - d * cw.w;
+        } else {
+            racc.x += gxp.x + d * xa.x; racc.y += gxp.y + d * xa.y; racc.z += gxp.z + d * xa.z; racc.w += gxp.w + d * xa.w;
+            racc2.x += d * x.x; racc2.y += d * x.y; racc2.z += d * x.z; racc2.w += d * x.w;
+        }
+        if (!more) break;
+        cur = nxt;
     }
-    pair_apply();
     flush_row(true);
 }
 
@@ -821,9 +844,22 @@ int pair_records_reduce(int model, int64_t M, int D, int rd, int64_t ent_total, 
     hipLaunchKernelGGL(bkt_sort_kernel, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
                        g_c.dst_sorted, g_c.ids_sorted, totals, cursor);
     PairRed pr;
-    pr.ent = tables[0]; pr.auxr = tables[2]; pr.auxe = tables[3];
+    pr.ent = tables[0]; pr.ctx = tables[2]; pr.auxe = tables[3];
     pr.g_ent = grads[0]; pr.g_auxe = grads[3];
     pr.D = D; pr.R = (int)rel_total; pr.RD = rd; pr.unit = unit;
+    pr.magic = rel_total == 1 ? 0xFFFFFFFFu : (unsigned)(((uint64_t(1) << 32) + (uint64_t)rel_total - 1) / (uint64_t)rel_total);
+    if (model == KGE_TRANSH) {   // normalised normal vectors, once per step
+        static float *ctxn = nullptr;
+        static int64_t ctxn_cap = 0;
+        if (rel_total * D > ctxn_cap) {
+            if ((rc = regrow(ctxn, (size_t)(rel_total * D), "normalised normal vectors"))) return rc;
+            ctxn_cap = rel_total * D;
+        }
+        int nb = (int)((rel_total + 3) / 4);
+        if (nb > 1024) nb = 1024;
+        hipLaunchKernelGGL(ctx_normalize_kernel, dim3(nb), dim3(256), 0, stream, tables[2], (int)rel_total, D, ctxn);
+        pr.ctx = ctxn;
+    }
     const long long chunks = (M + CHUNK - 1) / CHUNK;
     const long long nb = (chunks + 3) / 4;
     if (model == KGE_TRANSH)

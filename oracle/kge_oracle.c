@@ -531,13 +531,15 @@ static float forward_all(const OrcModel *M, const i64 *bh, const i64 *bt, const 
         }
         free(S);
     }
-    float total = 0.f;
+    /* the fp32 hinge values are added in double: a sequential fp32 sum of B*N ~ 10^5..10^6 terms is off by ~1e-5 relative on
+     * its own (TF's reduce_mean is a blocked / pairwise reduction, not a sequential one), which is the tolerance itself */
+    double total = 0.0;
     for (i64 b = 0; b < B; b++)
         for (i64 k = 0; k < N; k++) {
             float v = pos_score[b] - neg_score[b * N + k] + M->margin;
-            total += v > 0.f ? v : 0.f;
+            total += v > 0.f ? (double)v : 0.0;
         }
-    return total / (float)(B * N);
+    return (float)(total / (double)(B * N));
 }
 
 /* scores of the B positives and of the B*N negatives (ns[b*N+k]); lets a test see how close a hinge is to 0 */

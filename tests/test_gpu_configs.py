@@ -11,6 +11,7 @@ batch (Base.cpp:74-172), then loss, summed gradients and the SGD parameters (dis
 1e-5 relative tolerance of BASELINE.json's north_star.  Rows that fall outside it are COUNTED, reported, bounded and
 each one EXPLAINED: it must belong to a group in which an element of e = h^ + r^ - t^ is within fp32 rounding of zero
 (d|e|/de jumps there), which is a property of the loss, not of either implementation."""
+import os
 import numpy as np
 import pytest
 
@@ -24,9 +25,39 @@ KINK_TOL = 3e-7     # |e| below this: fp32 evaluations of e = h^ + r^ - t^ (|x^|
 KINK_TOL_TRANSR = 1e-6   # ... where h^, t^ come out of a 200-term projection summed in different orders (MFMA tiles vs a scalar loop)
 
 
-def near_ties(orc, bh, bt, br, B, N, eps=2e-6):
-    """hinges within fp32 rounding of the switch point (relative to the scores' magnitude ~2)"""
-    return int((np.abs(orc.hinge_margins(bh, bt, br, B, N)) < eps).sum())
+TIE_TOL = 1e-5   # |p - n + margin| below this: the two L1 scores (sums of D terms, added in different orders) may put the hinge on either side
+
+
+def tie_group_rows(hm, params, bh, bt, br, B, N, tol=TIE_TOL):
+    """{table: rows} of the groups with a hinge within `tol` of its switch point (hm = the oracle's hinge margins [B, N] at the
+    step's STARTING parameters): a flipped hinge switches the gradient rows of the whole (positive, negative) pair on or off,
+    which reaches every row of the group."""
+    hm = np.abs(hm)
+    groups = np.nonzero((hm < tol).any(1))[0]
+    rows = {k: set() for k in params}
+    idx = (groups[:, None] + B * np.arange(N + 1)[None, :]).ravel() if len(groups) else np.zeros(0, np.int64)
+    ents = set(np.asarray(bh)[idx].tolist()) | set(np.asarray(bt)[idx].tolist())
+    rels = set(np.asarray(br)[idx].tolist())
+    for k in rows:
+        rows[k] = set(ents) if k in ("ent_embeddings", "ent_transfer") else set(rels)
+    return rows, len(groups)
+
+
+def closest_switch_points(hm, model, params, bh, bt, br, B, N, dims, table, rows):
+    """diagnostics for an unexplained row: the smallest |hinge| and smallest |e| over the groups that touch it"""
+    from torch_ref import near_kink_rows
+    out = []
+    hm = np.abs(hm)
+    bh, bt, br = np.asarray(bh), np.asarray(bt), np.asarray(br)
+    for row in rows:
+        use = (br == row) if table in ("rel_embeddings", "normal_vectors", "rel_transfer", "transfer_matrix") else ((bh == row) | (bt == row))
+        groups = np.unique(np.nonzero(use)[0] % B)
+        idx = (groups[:, None] + B * np.arange(N + 1)[None, :]).ravel()
+        tol = 1e-4
+        while tol > 1e-9 and near_kink_rows(model, params, bh[idx], bt[idx], br[idx], len(groups), N, dims[0], dims[1], tol=tol)[1] > 0:
+            tol /= 2
+        out.append(dict(row=int(row), groups=len(groups), min_abs_hinge=float(hm[groups].min()), no_e_below=tol))
+    return out
 
 
 def check_sampled_batch(con, kg, B, n):
@@ -39,20 +70,22 @@ def check_sampled_batch(con, kg, B, n):
     return dev, bh, bt, br
 
 
-def run_steps(con, kg, orc, B, n, alpha, steps, name, model, dims):
+def run_steps(con, kg, orc, B, n, alpha, steps, name, model, dims, max_outside_rows=24):
     """`steps` SGD steps on device-sampled batches.  Every step the oracle starts from the ENGINE's current tables, so
     each comparison is of one forward/backward/update on identical inputs.  Rows outside 1e-5 must be explained: they
     have to be rows of a group in which some element of e = h^ + r^ - t^ lies within fp32 rounding of zero (fp64
-    evaluation, tests/torch_ref.py::near_kink_rows) -- the one place where two correct fp32 evaluations of this loss
-    legitimately differ by more than rounding."""
+    evaluation, tests/torch_ref.py::near_kink_rows), or of a group with a hinge p - n + margin within TIE_TOL of its switch
+    point (the two scores are sums of D terms added in different orders) -- the two places where two correct fp32
+    evaluations of this loss legitimately differ by more than rounding."""
     import torch
     from torch_ref import near_kink_rows
-    worst = dict(loss=0.0, grad=0.0, grad_rows=0, update_rows=0, ties=0, kink_elems=0)
+    worst = dict(loss=0.0, grad=0.0, grad_rows=0, update_rows=0, ties=0, kink_elems=0, tie_groups=0)
     for step in range(steps):
         start = con.get_parameters()
         orc.params = {k: v.copy() for k, v in start.items()}
         dev, bh, bt, br = check_sampled_batch(con, kg, B, n)
-        worst["ties"] += near_ties(orc, bh, bt, br, B, n)
+        hm = orc.hinge_margins(bh, bt, br, B, n)            # at the step's starting parameters (orc.params moves below)
+        worst["ties"] += int((np.abs(hm) < 2e-6).sum())
         loss_o, g_o = orc.grad(bh, bt, br, B, n)
         con.forward_backward(dev, B, B, B * n)
         torch.cuda.synchronize()
@@ -80,16 +113,37 @@ def run_steps(con, kg, orc, B, n, alpha, steps, name, model, dims):
                     kink, n_el = near_kink_rows(model, start, bh, bt, br, B, n, dims[0], dims[1],
                                                 tol=KINK_TOL_TRANSR if model == "transr" else KINK_TOL)
                     worst["kink_elems"] += n_el
+                    tied, n_tied = tie_group_rows(hm, start, bh, bt, br, B, n)
+                    worst["tie_groups"] += n_tied
+                    for kk in kink:
+                        kink[kk] |= tied[kk]
                 unexplained = (set(bad.tolist()) | set(bad_u.tolist())) - kink[k]
-                assert not unexplained, (name, step, k, sorted(unexplained)[:10], "rows outside 1e-5 with no |e| < KINK_TOL in their group")
+                if unexplained and os.environ.get("KGE_DUMP_UNEXPLAINED"):   # the groups touching the first such row, for offline study
+                    r0 = sorted(unexplained)[0]
+                    hh, tt, rr = np.asarray(bh), np.asarray(bt), np.asarray(br)
+                    gs = np.unique(np.nonzero((hh == r0) | (tt == r0))[0] % B)
+                    idx = (gs[:, None] + B * np.arange(n + 1)[None, :]).ravel()
+                    ents = np.unique(np.concatenate([hh[idx], tt[idx]])); rels = np.unique(rr[idx])
+                    np.savez(os.path.join(os.environ["KGE_DUMP_UNEXPLAINED"], "unexplained.npz"), row=r0, groups=gs, bh=hh[idx], bt=tt[idx], br=rr[idx],
+                             ents=ents, rels=rels, **{"ent_" + kk: start[kk][ents] for kk in start if start[kk].shape[0] == con.entTotal},
+                             **{"rel_" + kk: start[kk][rels] for kk in start if start[kk].shape[0] == con.relTotal},
+                             g_engine=g_g[k][ents], g_oracle=g_o[k][ents], hinge=hm[gs])
+                if unexplained:   # diagnostics on stdout (pytest shows it with the failure)
+                    print("UNEXPLAINED", closest_switch_points(hm, model, start, bh, bt, br, B, n, dims, k, sorted(unexplained)[:3]))
+                    print("UNEXPLAINED", [dict(row=r, grad_diff_over_scale=float(diff[r].max() / scale),
+                                               engine_norm=float(np.linalg.norm(g_g[k][r])), oracle_norm=float(np.linalg.norm(g_o[k][r])))
+                                          for r in sorted(unexplained)[:3]])
+                assert not unexplained, (name, step, k, sorted(unexplained)[:10],
+                                         "rows outside 1e-5 with no |e| < KINK_TOL and no hinge within TIE_TOL in their group")
     assert con.get_stream_states().tolist() == kg.stream_states().tolist()
     parity_report(name, batch=B, steps=steps, loss_relerr=worst["loss"], grad_relerr_other_rows=worst["grad"],
                   grad_rows_outside_1e5=worst["grad_rows"], update_rows_outside_1e5=worst["update_rows"],
-                  elements_of_e_within_tol_of_zero=worst["kink_elems"], tol=KINK_TOL, near_tie_hinges=worst["ties"])
+                  elements_of_e_within_tol_of_zero=worst["kink_elems"], tol=KINK_TOL, near_tie_hinges=worst["ties"],
+                  groups_with_hinge_within_tie_tol=worst["tie_groups"], tie_tol=TIE_TOL)
     assert worst["loss"] <= RTOL, worst
     assert worst["grad"] <= RTOL, worst
     # every outside row was explained above; bound their number too (a flipped element reaches the <= 6 rows of its group)
-    assert worst["grad_rows"] <= 6 * max(worst["kink_elems"], 0) and worst["grad_rows"] <= 24, worst
+    assert worst["grad_rows"] <= 6 * (worst["kink_elems"] + (2 + n) * worst["tie_groups"]) and worst["grad_rows"] <= max_outside_rows, worst
 
 
 def engine(path, model, dim, nbatches, n, alpha, bern=0):
@@ -118,6 +172,25 @@ def test_config3_wn18rr_transh(wn_dir, nbatches, B, path):
     kg.set_stream_states(con.get_stream_states())
     orc = oracle.Model("transh", con.entTotal, con.relTotal, 200, 200, margin=1.0, params=con.get_parameters())
     run_steps(con, kg, orc, B, n, alpha, steps=3, name="config3 WN18RR TransH D=200 B=%d (%s)" % (B, path), model="transh", dims=(200, 200))
+    _lib.raise_if_error(con.lib)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the projecting models with many negatives: the pair-count path (csrc/pairs.hip; chosen by the engine from 4 negatives and
+# 65 536 entity-side rows per step on)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model,graph,nbatches,B", [("TransH", "wn", 8, 10854), ("TransD", "fb", 32, 8503)])
+def test_pair_count_path_many_negatives(wn_dir, fb_dir, model, graph, nbatches, B):
+    from openkeonspark_amd import _lib
+    n, alpha = 25, 0.01
+    d = wn_dir if graph == "wn" else fb_dir
+    con = engine(d, model, 200, nbatches, n, alpha, bern=1)
+    assert con.batch_size == B and B * (2 + n) >= (1 << 16)
+    kg = oracle.KG(d, work_threads=8, bern=1)
+    kg.set_stream_states(con.get_stream_states())
+    orc = oracle.Model(model.lower(), con.entTotal, con.relTotal, 200, 200, margin=1.0, params=con.get_parameters())
+    run_steps(con, kg, orc, B, n, alpha, steps=2, name="%s D=200 n=25 B=%d on the %s-shaped graph (pair-count path)" % (model, B, graph),
+              model=model.lower(), dims=(200, 200), max_outside_rows=64)   # 26 scored triples per group: a flip reaches more rows
     _lib.raise_if_error(con.lib)
 
 
