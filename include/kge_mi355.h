@@ -211,6 +211,15 @@ int kge_forward_backward(const kge_model_desc *m, const float *const tables[KGE_
                          INT n_pos, INT n_neg, INT stride, INT denom,
                          float *const grads[KGE_MAX_TABLES], float *d_loss, void *stream);
 
+/* The same call for a batch the caller KNOWS to be sampler-shaped -- what kge_sampling_device / `sampling` produce
+ * (Base.cpp:109-139): every negative differs from its positive in exactly one entity slot, or (negative_rel) in the relation.
+ * Paths that route other groups to a separate exact pass (the TransH / TransD pair-count path) then skip that pass and
+ * its two bookkeeping launches.  A group that breaks the promise contributes nothing on those paths. */
+int kge_forward_backward_sampled(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES],
+                                 const int32_t *d_h, const int32_t *d_t, const int32_t *d_r,
+                                 INT n_pos, INT n_neg, INT stride, INT denom,
+                                 float *const grads[KGE_MAX_TABLES], float *d_loss, void *stream);
+
 /* GradientDescentOptimizer on the summed gradient: p -= lr*g; g = 0   (distribute_training.py:98) */
 int kge_sgd_update(float *d_p, float *d_g, int64_t n, float lr, void *stream);
 /* TF1 AdamOptimizer._apply_sparse_shared on the summed gradient (distribute_training.py:96): every

@@ -487,9 +487,12 @@ class Config(object):
             ev.record(self._side_stream)
         self._prefetched = (dev, n_pos, ev)
 
-    def forward_backward(self, dev_batch, n_pos, stride, denom):
-        """Add dLoss/dTables of the batch into the gradient accumulators; loss -> self._loss."""
-        _lib.check(self.lib.kge_forward_backward(ctypes.byref(self._desc), self._tab_ptrs,
+    def forward_backward(self, dev_batch, n_pos, stride, denom, sampler_shaped=False):
+        """Add dLoss/dTables of the batch into the gradient accumulators; loss -> self._loss.
+        sampler_shaped=True (a device-sampled batch): paths with a separate exact pass for other batches skip it
+        (include/kge_mi355.h kge_forward_backward_sampled)."""
+        fn = self.lib.kge_forward_backward_sampled if sampler_shaped else self.lib.kge_forward_backward
+        _lib.check(fn(ctypes.byref(self._desc), self._tab_ptrs,
                                                  dev_batch[0].data_ptr(), dev_batch[1].data_ptr(),
                                                  dev_batch[2].data_ptr(), n_pos,
                                                  self.negative_ent + self.negative_rel, stride, denom,
@@ -587,7 +590,7 @@ class Config(object):
             else:
                 self.apply_counts(denom)
         else:
-            self.forward_backward(dev, n_pos, stride, denom)
+            self.forward_backward(dev, n_pos, stride, denom, sampler_shaped=batch_h is None)
             if batch_h is None and self.prefetch_sampling:
                 self._prefetch_next_batch()
             if self.world_size > 1:

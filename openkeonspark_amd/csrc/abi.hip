@@ -353,7 +353,14 @@ int kge_forward_backward(const kge_model_desc *m, const float *const tables[KGE_
                          const int32_t *d_t, const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom,
                          float *const grads[KGE_MAX_TABLES], float *d_loss, void *stream) {
     if (!m || !tables || !grads || !d_loss) return fail(KGE_ERR_BAD_ARG, "kge_forward_backward: null argument");
-    return launch_forward_backward(*m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, grads, d_loss, (hipStream_t)stream);
+    return launch_forward_backward(*m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, grads, d_loss, (hipStream_t)stream, false);
+}
+
+int kge_forward_backward_sampled(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES], const int32_t *d_h,
+                                 const int32_t *d_t, const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom,
+                                 float *const grads[KGE_MAX_TABLES], float *d_loss, void *stream) {
+    if (!m || !tables || !grads || !d_loss) return fail(KGE_ERR_BAD_ARG, "kge_forward_backward_sampled: null argument");
+    return launch_forward_backward(*m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, grads, d_loss, (hipStream_t)stream, true);
 }
 
 int kge_sgd_update(float *d_p, float *d_g, int64_t n, float lr, void *stream) {

@@ -125,7 +125,7 @@ int launch_sampler(int32_t *d_h, int32_t *d_t, int32_t *d_r, int64_t B, int64_t 
 int launch_widen(const int32_t *src3, int64_t *dst3_and_y, int64_t B, int64_t total, hipStream_t stream);
 int launch_forward_backward(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
                             const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride, int64_t denom,
-                            float *const grads[4], float *d_loss, hipStream_t stream);
+                            float *const grads[4], float *d_loss, hipStream_t stream, bool sampler_shaped = false);
 int launch_predict(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
                    const int32_t *d_r, int64_t n, float *d_out, hipStream_t stream);
 int launch_lp_table(const kge_model_desc &m, const float *const tables[4], const float *P_all, int64_t r, float *T, hipStream_t stream);

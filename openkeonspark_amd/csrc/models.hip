@@ -688,9 +688,13 @@ __global__ __launch_bounds__(256) void hub_fold_kernel(float *__restrict__ copie
         if (!c) continue;
         const long long j = i < RD ? i : i - RD;
         float s = 0.f;
-        for (int k = 0; k < K; k++) {
-            const float v = c[k * RD + j];
-            if (v != 0.f) { s += v; c[k * RD + j] = 0.f; }
+        for (int k0 = 0; k0 < K; k0 += 8) {   // eight copies in flight (a chain of dependent loads made this small kernel take 27 us)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = c[(long long)min(k0 + u, K - 1) * RD + j];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (k0 + u < K && v[u] != 0.f) { s += v[u]; c[(long long)(k0 + u) * RD + j] = 0.f; }
         }
         if (s != 0.f) g[j] += s;
     }
@@ -788,7 +792,7 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
 
 int launch_forward_backward(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
                             const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride, int64_t denom,
-                            float *const grads[4], float *d_loss, hipStream_t stream) {
+                            float *const grads[4], float *d_loss, hipStream_t stream, bool sampler_shaped) {
     Engine &e = engine();
     if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_forward_backward: no usable HIP device");
     if (n_pos < 0 || n_neg < 1 || stride < n_pos || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_forward_backward: bad sizes");
@@ -811,26 +815,32 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
         const int64_t M = n_pos * (2 + n_neg);
         const int rd = pair_record_dwords(a.D);
         if ((rc = pair_records_workspace(M, rd, a.rec, a.dst))) return rc;
-        if (n_pos > g_defer_cap) {
-            if (g_defer_list) (void)hipFree(g_defer_list);
-            g_defer_list = nullptr;
-            if ((rc = hip_check(hipMalloc(&g_defer_list, sizeof(int32_t) * (size_t)n_pos), "alloc deferred groups"))) return rc;
-            if (!g_defer_count && (rc = hip_check(hipMalloc(&g_defer_count, sizeof(int32_t)), "alloc deferred count"))) return rc;
-            g_defer_cap = n_pos;
-        }
-        if ((rc = hip_check(hipMemsetAsync(g_defer_count, 0, sizeof(int32_t), stream), "zero deferred count"))) return rc;
-        a.group_list = g_defer_list; a.group_count = g_defer_count;
         a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total;
         if ((rc = attach_hub_copies(m, n_pos, a))) return rc;
         guard_loss_stream(stream);
-        launch_pair_emit(m.model, a, stream);
-        // groups with negatives that are not sampler-shaped: the exact fp32 kernel (atomic adds), its partial losses behind the emit's
-        FbArgs d = a;
-        d.loss_partials = a.loss_partials + pair_emit_blocks(n_pos);
-        rc = m.model == KGE_TRANSH ? dispatch_fb_deferred<KGE_TRANSH>(d, stream) : dispatch_fb_deferred<KGE_TRANSD>(d, stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, a.loss_partials, (int)pair_emit_blocks(n_pos) + kDeferBlocks,
-                           a.unit, d_loss);
+        if (sampler_shaped) {
+            // the caller vouches for the batch: no deferral list, the emit kernel's last workgroup writes the loss
+            a.loss_out = d_loss; a.loss_ticket = e.dev.loss_ticket;
+            launch_pair_emit(m.model, a, stream);
+        } else {
+            if (n_pos > g_defer_cap) {
+                if (g_defer_list) (void)hipFree(g_defer_list);
+                g_defer_list = nullptr;
+                if ((rc = hip_check(hipMalloc(&g_defer_list, sizeof(int32_t) * (size_t)n_pos), "alloc deferred groups"))) return rc;
+                if (!g_defer_count && (rc = hip_check(hipMalloc(&g_defer_count, sizeof(int32_t)), "alloc deferred count"))) return rc;
+                g_defer_cap = n_pos;
+            }
+            if ((rc = hip_check(hipMemsetAsync(g_defer_count, 0, sizeof(int32_t), stream), "zero deferred count"))) return rc;
+            a.group_list = g_defer_list; a.group_count = g_defer_count;
+            launch_pair_emit(m.model, a, stream);
+            // groups with negatives that are not sampler-shaped: the exact fp32 kernel (atomic adds), its partial losses behind the emit's
+            FbArgs d = a;
+            d.loss_partials = a.loss_partials + pair_emit_blocks(n_pos);
+            rc = m.model == KGE_TRANSH ? dispatch_fb_deferred<KGE_TRANSH>(d, stream) : dispatch_fb_deferred<KGE_TRANSD>(d, stream);
+            if (rc) return rc;
+            hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, a.loss_partials, (int)pair_emit_blocks(n_pos) + kDeferBlocks,
+                               a.unit, d_loss);
+        }
         if ((rc = pair_records_reduce(m.model, M, a.D, rd, m.ent_total, m.rel_total, tables, grads, a.unit, stream))) return rc;
         if (a.copies_rel) {
             const long long RD = (long long)m.rel_total * a.D;

@@ -95,7 +95,7 @@ __device__ __forceinline__ void project(const float (&x)[E], const float (&xa)[E
     }
     const float ss = dot16<E>(xp, xp);
     uc = ss >= 1e-12f;
-    inv = 1.0f / sqrtf(uc ? ss : 1e-12f);
+    inv = fast_rsqrt(uc ? ss : 1e-12f);
 }
 
 }  // namespace
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void pair_emit_kernel(FbArgs a) {
         }
         if (team_sum<PT>(bad) != 0.f) {   // the whole group goes to the exact fp32 kernel
             for (long long sl = lane; sl < 2 + a.n_neg; sl += PT) a.dst[sl * a.n_pos + b] = -1;
-            if (lane == 0) a.group_list[atomicAdd(a.group_count, 1)] = (int32_t)b;
+            if (lane == 0 && a.group_list) a.group_list[atomicAdd(a.group_count, 1)] = (int32_t)b;   // (no list: the caller vouched for the batch)
             continue;
         }
         // ---- relation context ----

@@ -37,6 +37,14 @@ __device__ __forceinline__ float team_sum(float v) {
     return v;
 }
 
+// 1/sqrt(x) for x >= 1e-12: the hardware estimate (1 ulp) refined by one Newton step -- 5 instructions where the IEEE
+// sqrt + divide sequence takes ~25 (it sits in the per-negative path of the pair-count kernels; results agree with
+// 1.0f / sqrtf(x) to the last bit or two, far inside the 1e-5 parity tolerance)
+__device__ __forceinline__ float fast_rsqrt(float x) {
+    float y = __builtin_amdgcn_rsqf(x);
+    return y * (1.5f - 0.5f * x * y * y);
+}
+
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f ? 1.f : 0.f) - (x < 0.f ? 1.f : 0.f); }
 
 template <int L, int C>

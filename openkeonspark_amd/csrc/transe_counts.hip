@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256) void segsum_pairs_kernel(const uint32_t *__res
         float ss = dot4(xp, xp), dp = dot4(xp, S);
         ss = team_sum<L>(ss); dp = team_sum<L>(dp);
         const bool uc = ss >= 1e-12f;
-        const float inv = 1.0f / sqrtf(uc ? ss : 1e-12f);
+        const float inv = fast_rsqrt(uc ? ss : 1e-12f);
         const float al = uc ? inv * pr.unit * dp : 0.f;       // <nrm, G>,  G = unit S
         const float cg = inv * pr.unit, cx = -inv * inv * al;   // gxp = inv (G - al nrm) = cg S + cx xp
         const float4 gxp = make_float4(cg * S.x + cx * xp.x, cg * S.y + cx * xp.y, cg * S.z + cx * xp.z, cg * S.w + cx * xp.w);
