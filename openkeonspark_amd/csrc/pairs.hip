@@ -220,20 +220,8 @@ __global__ __launch_bounds__(256, 2) void pair_emit_kernel(FbArgs a) {
                 my_row = nh != h ? nh : nt;
             }
             const int in_round = min(PT, (int)a.n_neg - k0);
-            float x[E], xa[E], x1[E], xa1[E];   // this negative's row(s) and the next one's
-            int row = __shfl(my_row, 0, PT), code = __shfl(my_code, 0, PT);
-            load_row<Q>(a.ent, row, D, lane, x);
-            if constexpr (MODEL == KGE_TRANSD) load_row<Q>(a.auxe, row, D, lane, xa);
-            int row1 = __shfl(my_row, min(1, in_round - 1), PT), code1 = __shfl(my_code, min(1, in_round - 1), PT);
-            load_row<Q>(a.ent, row1, D, lane, x1);
-            if constexpr (MODEL == KGE_TRANSD) load_row<Q>(a.auxe, row1, D, lane, xa1);
-            for (int kk = 0; kk < in_round; kk++) {
-                // two rows ahead on their way while this negative is scored (the gather, not the arithmetic, bounds the kernel)
-                const int nsrc = min(kk + 2, in_round - 1);
-                const int nrow = __shfl(my_row, nsrc, PT), ncode = __shfl(my_code, nsrc, PT);
-                float xn[E], xan[E];
-                load_row<Q>(a.ent, nrow, D, lane, xn);
-                if constexpr (MODEL == KGE_TRANSD) load_row<Q>(a.auxe, nrow, D, lane, xan);
+            // one negative: forward, hinge, sign record, integer sums, relation-context gradient
+            auto score_negative = [&](const float (&x)[E], const float (&xa)[E], int row, int code, int kk) {
                 float xp[E];
                 float aa, inv; bool uc;
                 project<MODEL, E>(x, xa, cw, xp, aa, inv, uc);
@@ -281,12 +269,26 @@ __global__ __launch_bounds__(256, 2) void pair_emit_kernel(FbArgs a) {
                 }
                 context_grad(x, xp, gf, aa, inv, uc);   // (all zero when inactive: g = 0)
                 if (lane == kk) my_dst = act ? (int)((long long)row * R + r) : -1;
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    x[e] = x1[e]; x1[e] = xn[e];
-                    if constexpr (MODEL == KGE_TRANSD) { xa[e] = xa1[e]; xa1[e] = xan[e]; }
+            };
+            // Two row buffers used alternately (the loop is unrolled by two, so no register moves): while a negative is scored
+            // the next one's row(s) are on their way.  A deeper queue did not pay (measured): the kernel is bound by issue, not
+            // by the number of gathers in flight.
+            float xA[E], xaA[E], xB[E], xaB[E];
+            auto fetch = [&](int kk, float (&x)[E], float (&xa)[E], int &row, int &code) {
+                const int src = min(kk, in_round - 1);
+                row = __shfl(my_row, src, PT); code = __shfl(my_code, src, PT);
+                load_row<Q>(a.ent, row, D, lane, x);
+                if constexpr (MODEL == KGE_TRANSD) load_row<Q>(a.auxe, row, D, lane, xa);
+            };
+            int rowA, codeA, rowB, codeB;
+            fetch(0, xA, xaA, rowA, codeA);
+            for (int kk = 0; kk < in_round; kk += 2) {
+                fetch(kk + 1, xB, xaB, rowB, codeB);
+                score_negative(xA, xaA, rowA, codeA, kk);
+                if (kk + 1 < in_round) {
+                    fetch(kk + 2, xA, xaA, rowA, codeA);
+                    score_negative(xB, xaB, rowB, codeB, kk + 1);
                 }
-                row = row1; code = code1; row1 = nrow; code1 = ncode;
             }
             if (k0 + lane < (int)a.n_neg) a.dst[(long long)(2 + k0 + lane) * a.n_pos + b] = my_dst;
         }
