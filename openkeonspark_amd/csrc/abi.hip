@@ -225,6 +225,7 @@ int kge_set_option(const char *name, INT value) {
     if (n == "index_device_min") { engine().index_device_min = value; return KGE_OK; }
     if (n == "hub_copies") { engine().hub_copies = value != 0; return KGE_OK; }
     if (n == "pair_counts") { engine().pair_counts = value != 0; return KGE_OK; }
+    if (n == "transr_lean") { engine().transr_lean = value != 0; return KGE_OK; }
     if (n == "pair_counts_min_neg") { engine().pair_counts_min_neg = (int)value; return KGE_OK; }
     if (n == "lp_v1") { engine().lp_v1 = value != 0; return KGE_OK; }
     if (n == "transr_v1") { engine().transr_v1 = (int)value; return KGE_OK; }

@@ -768,11 +768,163 @@ static int dispatch_fb_deferred(const FbArgs &a, hipStream_t stream) {
     return KGE_OK;
 }
 
+// ---- TransR vector stage, lean form (rel_dim a multiple of 4 up to 1024; sampler-shaped groups) ------------------------------
+// One wave per positive and its negatives over the PROJECTED rows P (written by the project GEMM, TransR.py:16-17): normalise,
+// L1 score, hinge, and the normalise-backward of +-unit*sign(e) into GP (read by dgrad / wgrad).  Lane l holds the float4 chunks
+// l, l+64, ... of a row (one 16-byte load or store per row chunk; the generic fwdbwd_kernel<TRANSR> issues four strided
+// conditional loads per row, each compiled into its own branch + wait).  Every GP row dgrad / wgrad will read is WRITTEN here --
+// zeros when the hinge is inactive -- so GP needs no memset.  Groups with a negative that is not entity-corrupted with the
+// positive's matrix go to the generic kernel (a.group_list), after their GP rows have been zeroed here.
+template <int Q>
+__global__ __launch_bounds__(256) void transr_vec_kernel(FbArgs a) {
+    constexpr int L = 64, TEAMS = 4, E = 4 * Q;
+    __shared__ float red[TEAMS];
+    __shared__ float add_stage[TEAMS][L * E];
+    const int lane = threadIdx.x % L, team_in_block = threadIdx.x / L;
+    const int D = a.D;
+    auto load = [&](const float *__restrict__ tab, long long row, float (&x)[E]) {
+        const float *p = tab + row * D;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int e0 = 4 * (lane + L * q);
+            const bool ok = e0 < D;
+            const float4 v = *reinterpret_cast<const float4 *>(p + (ok ? e0 : 0));   // clamped + select: no branch around the load
+            x[4 * q] = ok ? v.x : 0.f; x[4 * q + 1] = ok ? v.y : 0.f; x[4 * q + 2] = ok ? v.z : 0.f; x[4 * q + 3] = ok ? v.w : 0.f;
+        }
+    };
+    auto store = [&](float *__restrict__ tab, long long row, const float (&x)[E]) {
+        float *p = tab + row * D;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int e0 = 4 * (lane + L * q);
+            if (e0 < D) *reinterpret_cast<float4 *>(p + e0) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+        }
+    };
+    auto dot = [&](const float (&x)[E], const float (&y)[E]) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; e++) s += x[e] * y[e];
+        return team_sum<L>(s);
+    };
+    auto normalize = [&](float (&x)[E], float &inv, bool &uc) {   // in place
+        const float ss = dot(x, x);
+        uc = ss >= 1e-12f;
+        inv = 1.0f / sqrtf(uc ? ss : 1e-12f);
+#pragma unroll
+        for (int e = 0; e < E; e++) x[e] *= inv;
+    };
+    // gx = inv (G - y <y, G>) with G = unit * g
+    auto normalize_bwd = [&](const float (&y)[E], const float (&g)[E], float inv, bool uc, float (&gx)[E]) {
+        float d = dot(y, g) * a.unit;
+        if (!uc) d = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; e++) gx[e] = inv * (a.unit * g[e] - d * y[e]);
+    };
+    float zero[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) zero[e] = 0.f;
+    float lsum = 0.f;
+    for (long long b = (long long)blockIdx.x * TEAMS + team_in_block; b < a.n_pos; b += (long long)gridDim.x * TEAMS) {
+        const int h = a.bh[b], t = a.bt[b], r = a.br[b];
+        // ---- every negative entity-corrupted, scored with the positive's matrix? ----
+        float bad = 0.f;
+        for (int k = lane; k < (int)a.n_neg; k += L) {
+            const long long j = b + (long long)(k + 1) * a.stride;
+            const NegClass nc = classify_negative<KGE_TRANSR>(h, t, r, a.bh[j], a.bt[j], a.br[j], a.negative_rel);
+            if (!nc.fast || nc.same_h == nc.same_t) bad = 1.f;
+        }
+        if (team_sum<L>(bad) != 0.f) {
+            // the generic kernel writes the rows of its active hinges; everything dgrad / wgrad may read of this group is zeroed first
+            for (long long k = 0; k <= a.n_neg; k++) {
+                const long long sl = 2 * (k * a.n_pos + b);
+                store(a.GP, sl, zero); store(a.GP, sl + 1, zero);
+            }
+            if (lane == 0 && a.group_list) a.group_list[atomicAdd(a.group_count, 1)] = (int32_t)b;
+            continue;
+        }
+        float rn[E], hn[E], tn[E];
+        float inv_r, inv_h, inv_t; bool uc_r, uc_h, uc_t;
+        load(a.rel, r, rn); load(a.P, 2 * b, hn); load(a.P, 2 * b + 1, tn);
+        normalize(rn, inv_r, uc_r); normalize(hn, inv_h, uc_h); normalize(tn, inv_t, uc_t);
+        float sp[E], Ah[E], At[E], Ar[E];
+        float p;
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; e++) { const float ev = hn[e] + rn[e] - tn[e]; acc += fabsf(ev); sp[e] = sgn(ev); Ah[e] = 0.f; At[e] = 0.f; Ar[e] = 0.f; }
+            p = team_sum<L>(acc);
+        }
+        int cnt = 0;
+        for (long long k = 0; k < a.n_neg; k++) {
+            const long long j = b + (k + 1) * a.stride;
+            const bool new_head = a.bh[j] != h;
+            const long long slot = 2 * ((k + 1) * a.n_pos + b) + (new_head ? 0 : 1);   // the corrupted side's projected row
+            float xn[E], sg[E];
+            float inv; bool uc;
+            load(a.P, slot, xn);
+            normalize(xn, inv, uc);
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const float ev = new_head ? xn[e] + rn[e] - tn[e] : hn[e] + rn[e] - xn[e];
+                acc += fabsf(ev); sg[e] = sgn(ev);
+            }
+            const float nk = team_sum<L>(acc);
+            const float v = p - nk + a.margin;
+            if (v >= 0.f) {
+                cnt++; lsum += v;
+                float g[E], gx[E];
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    // new head: dL/dx^ = -s, the kept t gets +s ; new tail: +s, the kept h gets -s ; r^ gets -s either way
+                    g[e] = new_head ? -sg[e] : sg[e];
+                    if (new_head) At[e] += sg[e]; else Ah[e] -= sg[e];
+                    Ar[e] -= sg[e];
+                }
+                normalize_bwd(xn, g, inv, uc, gx);
+                store(a.GP, slot, gx);
+            } else {
+                store(a.GP, slot, zero);
+            }
+        }
+        if (cnt == 0) { store(a.GP, 2 * b, zero); store(a.GP, 2 * b + 1, zero); continue; }
+        const float fc = (float)cnt;
+        float g[E], gx[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) g[e] = Ah[e] + fc * sp[e];
+        normalize_bwd(hn, g, inv_h, uc_h, gx);
+        store(a.GP, 2 * b, gx);
+#pragma unroll
+        for (int e = 0; e < E; e++) g[e] = At[e] - fc * sp[e];
+        normalize_bwd(tn, g, inv_t, uc_t, gx);
+        store(a.GP, 2 * b + 1, gx);
+#pragma unroll
+        for (int e = 0; e < E; e++) g[e] = Ar[e] + fc * sp[e];
+        normalize_bwd(rn, g, inv_r, uc_r, gx);
+        {   // g_rel[r] += gx, contiguous per instruction (memory-side atomics are served per line touched: see flush_run)
+            float *stage = add_stage[team_in_block];
+#pragma unroll
+            for (int q = 0; q < Q; q++)
+                *reinterpret_cast<float4 *>(stage + 4 * (lane + L * q)) = make_float4(gx[4 * q], gx[4 * q + 1], gx[4 * q + 2], gx[4 * q + 3]);
+            // relation rows are hubs (a Zipf head relation takes a sixth of the batch): same-address atomics serialise, so group b
+            // adds into copy b % hub_k, folded afterwards (hub_fold_kernel)
+            float *pr = (a.copies_rel ? a.copies_rel + (b % a.hub_k) * (long long)a.rel_total * D : a.g_rel) + (long long)r * D;
+#pragma unroll
+            for (int c = 0; c < E; c++) {
+                const int e = lane + L * c;
+                const float v = stage[e];
+                if (e < D) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(pr + e), v);
+            }
+        }
+    }
+    finish_loss<TEAMS>(a, red, lsum, lane, team_in_block);
+}
+
 // TransR: the score / hinge / backward over the projected vectors (transr.hip runs the GEMMs around it)
 int launch_transr_vector_stage(const float *rel, float *g_rel, const float *P, float *GP, const int32_t *d_h,
                                const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
                                int64_t denom, int rel_dim, float margin, int negative_rel, float *d_loss,
-                               hipStream_t stream) {
+                               hipStream_t stream, bool lean, bool sampler_shaped, int64_t rel_total) {
     Engine &e = engine();
     FbArgs a = {};
     a.rel = rel; a.g_rel = g_rel; a.P = P; a.GP = GP;
@@ -781,14 +933,63 @@ int launch_transr_vector_stage(const float *rel, float *g_rel, const float *P, f
     a.D = rel_dim; a.margin = margin; a.unit = 1.0f / (float)denom;
     a.loss_partials = e.dev.loss_partials;
     a.negative_rel = negative_rel;
-    int rc = dispatch_fb<KGE_TRANSR>(a, d_loss, stream);
+    int rc;
+    if (lean) {   // every GP row read later is written by the kernel itself (the caller skipped the memset)
+        constexpr int TEAMS = 4;
+        {
+            kge_model_desc md = {};
+            md.model = KGE_TRANSR; md.rel_total = rel_total;
+            if ((rc = attach_hub_copies(md, n_pos, a))) return rc;   // a.D = rel_dim: [hub_k][R][rel_dim] copies of g_rel
+        }
+        long long blocks = (n_pos + TEAMS - 1) / TEAMS;
+        if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
+        if (blocks < 1) blocks = 1;
+        guard_loss_stream(stream);
+        const int Q = (rel_dim / 4 + 63) / 64;
+        auto launch = [&](const FbArgs &f) {
+            if (Q == 1) hipLaunchKernelGGL((transr_vec_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
+            else if (Q == 2) hipLaunchKernelGGL((transr_vec_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
+            else hipLaunchKernelGGL((transr_vec_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, stream, f);
+        };
+        if (sampler_shaped) {   // the caller vouches for the batch: the kernel's last workgroup writes the loss
+            a.loss_out = d_loss; a.loss_ticket = e.dev.loss_ticket;
+            launch(a);
+        } else {
+            if (n_pos > g_defer_cap) {
+                if (g_defer_list) (void)hipFree(g_defer_list);
+                g_defer_list = nullptr;
+                if ((rc = hip_check(hipMalloc(&g_defer_list, sizeof(int32_t) * (size_t)n_pos), "alloc deferred groups"))) return rc;
+                if (!g_defer_count && (rc = hip_check(hipMalloc(&g_defer_count, sizeof(int32_t)), "alloc deferred count"))) return rc;
+                g_defer_cap = n_pos;
+            }
+            if ((rc = hip_check(hipMemsetAsync(g_defer_count, 0, sizeof(int32_t), stream), "zero deferred count"))) return rc;
+            a.group_list = g_defer_list; a.group_count = g_defer_count;
+            launch(a);
+            FbArgs d = a;
+            d.loss_partials = a.loss_partials + blocks;
+            if ((rc = dispatch_fb_deferred<KGE_TRANSR>(d, stream))) return rc;
+            hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, a.loss_partials, (int)blocks + kDeferBlocks, a.unit, d_loss);
+        }
+        if (a.copies_rel) {
+            const long long RD = (long long)rel_total * rel_dim;
+            long long nb = (RD + 255) / 256;
+            if (nb > 1024) nb = 1024;
+            hipLaunchKernelGGL(hub_fold_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.copies_rel, (float *)nullptr, g_rel, (float *)nullptr,
+                               a.hub_k, RD);
+        }
+        return hip_check(hipGetLastError(), "transr vector stage launch");
+    }
+    rc = dispatch_fb<KGE_TRANSR>(a, d_loss, stream);
     if (rc) return rc;
     return hip_check(hipGetLastError(), "transr vector stage launch");
 }
 
+// the lean vector stage writes every GP row that is read afterwards (no memset needed): rel_dim a multiple of 4 up to 1024
+bool transr_lean_vector_stage(int rel_dim) { return engine().transr_lean && rel_dim % 4 == 0 && rel_dim >= 4 && rel_dim <= 1024; }
+
 int launch_forward_backward_transr(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h,
                                    const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
-                                   int64_t denom, float *const grads[4], float *d_loss, hipStream_t stream);
+                                   int64_t denom, float *const grads[4], float *d_loss, hipStream_t stream, bool sampler_shaped);
 
 int launch_forward_backward(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
                             const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride, int64_t denom,
@@ -798,7 +999,7 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
     if (n_pos < 0 || n_neg < 1 || stride < n_pos || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_forward_backward: bad sizes");
     { int rc = ensure_loss_buffers(); if (rc) return rc; }
     if (m.model == KGE_TRANSR)
-        return launch_forward_backward_transr(m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, grads, d_loss, stream);
+        return launch_forward_backward_transr(m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, grads, d_loss, stream, sampler_shaped);
     if (m.ent_dim != m.rel_dim) return fail(KGE_ERR_BAD_ARG, "TransE/H/D need ent_dim == rel_dim (hidden_size)");
     FbArgs a = {};
     a.ent = tables[0]; a.rel = tables[1]; a.auxr = tables[2]; a.auxe = tables[3];

@@ -29,7 +29,8 @@ namespace kge {
 int launch_transr_vector_stage(const float *rel, float *g_rel, const float *P, float *GP, const int32_t *d_h,
                                const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
                                int64_t denom, int rel_dim, float margin, int negative_rel, float *d_loss,
-                               hipStream_t stream);
+                               hipStream_t stream, bool lean, bool sampler_shaped, int64_t rel_total);
+bool transr_lean_vector_stage(int rel_dim);
 int launch_transr_predict_stage(const float *rel, const float *P, const int32_t *d_r, int64_t n, int rel_dim, float *d_out,
                                 hipStream_t stream);
 
@@ -749,7 +750,7 @@ int bits_for(int64_t v) { int b = 1; while ((int64_t(1) << b) <= v) b++; return 
 
 int launch_forward_backward_transr(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h,
                                    const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
-                                   int64_t denom, float *const grads[4], float *d_loss, hipStream_t stream) {
+                                   int64_t denom, float *const grads[4], float *d_loss, hipStream_t stream, bool sampler_shaped) {
     const int De = m.ent_dim, Dr = m.rel_dim;
     const int64_t R = m.rel_total;
     if (Dr > 1024) return fail(KGE_ERR_UNSUPPORTED, "TransR rel_dim > 1024 is not supported");
@@ -793,10 +794,10 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     if (v2 && Dr <= 112) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, 7>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
     else if (v2) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, 13>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
     else hipLaunchKernelGGL((rows_gemm_kernel<GEMM_PROJECT>), dim3(max_tiles, (Dr + TN - 1) / TN), dim3(256), 0, stream, ga);
-    rc = hip_check(hipMemsetAsync(g_w.GP, 0, sizeof(float) * (size_t)slots * Dr, stream), "zero GP");
-    if (rc) return rc;
+    const bool lean = transr_lean_vector_stage(Dr);   // the lean vector stage writes every GP row that dgrad / wgrad read
+    if (!lean && (rc = hip_check(hipMemsetAsync(g_w.GP, 0, sizeof(float) * (size_t)slots * Dr, stream), "zero GP"))) return rc;
     rc = launch_transr_vector_stage(tables[1], grads[1], g_w.P, g_w.GP, d_h, d_t, d_r, n_pos, n_neg, stride, denom, Dr, m.margin,
-                                    m.negative_rel, d_loss, stream);
+                                    m.negative_rel, d_loss, stream, lean, sampler_shaped, R);
     if (rc) return rc;
     if (v2) {
         if (De <= 112) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 7>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
