@@ -335,7 +335,7 @@ def main_fun(argv):
     t0 = time.time()
     g = last_global_step
     while g < iterations:
-        if not distributed and con.persistent_supported():
+        if not distributed and con.persistent_preferred():
             # launch-latency-bound step sizes: every step up to the next checkpoint / early-stop check in ONE persistent launch
             # (csrc/persist.hip); the per-step log lines of distribute_training.py:283 are printed from the returned losses
             to_epoch = con.nbatches - (g - last_global_step) % con.nbatches
