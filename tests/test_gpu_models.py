@@ -597,3 +597,44 @@ def test_negative_zero_has_sign_zero(D, reducer):
     parity_report("negative_zero_sign[D=%d %s]" % (D, reducer), rows_differing=len(bad_rows), bound_rows=EXACT_COUNT_ROWS_BOUND)
     assert len(bad_rows) <= EXACT_COUNT_ROWS_BOUND
     con._counts.zero_()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,Dr", [("transh", None), ("transd", None), ("transr", 64)])
+def test_sampled_entry_equals_general_entry(model, Dr):
+    """kge_forward_backward_sampled (the caller vouches that the batch is sampler-shaped: include/kge_mi355.h) against
+    kge_forward_backward on such a batch: same loss and gradients, for the paths that skip their exact pass (the TransH /
+    TransD pair-count path, TransR's lean vector stage), and both against the oracle."""
+    import torch
+    from openkeonspark_amd import _lib
+    L = _lib.lib()
+    E, R, D, B, n = 300, 9, 72, 700, 5
+    rng = np.random.default_rng(seed_of(model, "sampled-entry"))
+    dr = D if Dr is None else Dr
+    params = oracle.init_params(oracle.MODEL_IDS[model], E, R, D, dr, seed=12)
+    for k in params:
+        params[k] = (params[k] * 3).astype(np.float32)
+    orc = oracle.Model(model, E, R, D, dr, margin=1.5, params=params)
+    bh, bt, br = batch_without_ties(orc, lambda: rand_batch(rng, E, R, B, n, 0, distinct=True), B, n)
+    loss_o, g_o = orc.grad(bh, bt, br, B, n)
+    L.kge_set_option(b"float_records_min", 0)
+    L.kge_set_option(b"pair_counts_min_neg", 1)
+    try:
+        con = make_engine(model, E, R, D, n, 0, margin=1.5, params=params, Dr=Dr)
+        dev = torch.from_numpy(np.stack([bh, bt, br]).astype(np.int32)).cuda()
+        got = {}
+        for sampled in (False, True, True):          # twice: buffers the sampled entry leaves behind must be reusable
+            for g in con._grads:
+                g.zero_()
+            con.forward_backward(dev, B, B, B * n, sampler_shaped=sampled)
+            torch.cuda.synchronize()
+            got[sampled] = (float(con._loss.item()), con.get_gradients())
+            assert abs(got[sampled][0] - loss_o) <= RTOL * abs(loss_o)
+            for k in g_o:
+                assert relerr(got[sampled][1][k], g_o[k]) < RTOL, (sampled, k, relerr(got[sampled][1][k], g_o[k]))
+        assert abs(got[True][0] - got[False][0]) <= 1e-6 * abs(got[False][0])
+        for k in g_o:
+            assert relerr(got[True][1][k], got[False][1][k]) < 1e-6, k
+    finally:
+        L.kge_set_option(b"float_records_min", 1 << 16)
+        L.kge_set_option(b"pair_counts_min_neg", 4)
