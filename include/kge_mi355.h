@@ -116,7 +116,7 @@ const char *kge_version(void);
  *                        them by destination after a sort; 0 = fp32 atomic adds straight into the accumulators
  *   "float_records_min": smallest number of gradient rows per step that takes the record path (default 65536: measured cross-over, tools/sweep_paths.py)
  *   "pair_counts":       1 (default) = TransH / TransD steps of at least float_records_min entity-side rows (widths that are
- *                        multiples of 4 up to 256, at most 63 negatives, ent_total*rel_total sortable by the counting sort) take the
+ *                        multiples of 4 up to 256, at most 63 negatives, ent_total*rel_total below 2^31) take the
  *                        pair-count path: int8 sign records keyed by (entity, relation), the backward applied once per pair
  *                        (csrc/pairs.hip); 0 = float records / atomics as for the other shapes
  *   "pair_counts_min_neg": fewest negatives per positive for that path (default 4)

@@ -132,18 +132,19 @@ def test_transr_forward_backward_matches_oracle(E, R, De, Dr, n, nr, foreign, tr
         assert relerr(g_g[k], g_o[k]) < RTOL, (k, relerr(g_g[k], g_o[k]))
 
 
-@pytest.fixture(params=["atomic", "records-bucket", "records-sort", "pairs"])
+@pytest.fixture(params=["atomic", "records-bucket", "records-sort", "pairs", "pairs-sort"])
 def grad_path(request):
     """The accumulations of the gradient rows: memory-side fp32 atomics; float records ordered by the two-level counting
     sort / by rocPRIM's radix sort and summed by segments; and, for TransH / TransD at widths that are multiples of 4 up to
     256, int8 sign records keyed by (entity, relation) with the backward applied once per pair (the default on large steps;
-    other models and widths fall through to the float records)."""
+    other models and widths fall through to the float records), their keys ordered by the counting sort or (key spaces
+    beyond 4.2 M pairs; forced here) by rocPRIM's radix sort."""
     from openkeonspark_amd import _lib
     L = _lib.lib()
     L.kge_set_option(b"float_records", 0 if request.param == "atomic" else 1)
     L.kge_set_option(b"float_records_min", 0)
-    L.kge_set_option(b"counts_force_sort", 1 if request.param == "records-sort" else 0)
-    L.kge_set_option(b"pair_counts", 1 if request.param == "pairs" else 0)
+    L.kge_set_option(b"counts_force_sort", 1 if request.param in ("records-sort", "pairs-sort") else 0)
+    L.kge_set_option(b"pair_counts", 1 if request.param in ("pairs", "pairs-sort") else 0)
     L.kge_set_option(b"pair_counts_min_neg", 1)
     yield request.param
     L.kge_set_option(b"float_records", 1)
