@@ -639,3 +639,36 @@ def test_sampled_entry_equals_general_entry(model, Dr):
     finally:
         L.kge_set_option(b"float_records_min", 1 << 16)
         L.kge_set_option(b"pair_counts_min_neg", 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["transh", "transd"])
+@pytest.mark.parametrize("E,R,D,B,n", [(50, 1, 4, 300, 4), (120, 3, 256, 200, 17), (90, 5, 64, 150, 63), (300, 7, 132, 257, 16)])
+def test_pair_count_path_shapes(model, E, R, D, B, n):
+    """Edges of the pair-count path (csrc/pairs.hip): one float4 chunk per row and four, a single relation, 16 / 17 / 63
+    negatives (one full round of a 16-lane team, a second round with one negative, the maximum; int8 sums of 2n = 126),
+    widths that leave the last chunk partly empty.  Arbitrary negatives in 5 % of the slots go to the exact pass."""
+    import torch
+    from openkeonspark_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(seed_of(model, E, R, D, B, n, "pair-shapes"))
+    params = oracle.init_params(oracle.MODEL_IDS[model], E, R, D, D, seed=14)
+    for k in params:
+        params[k] = (params[k] * 3).astype(np.float32)
+    orc = oracle.Model(model, E, R, D, D, margin=1.0, params=params)
+    bh, bt, br = batch_without_ties(orc, lambda: rand_batch(rng, E, R, B, n, 0, 0.05), B, n)
+    loss_o, g_o = orc.grad(bh, bt, br, B, n)
+    L.kge_set_option(b"float_records_min", 0)
+    L.kge_set_option(b"pair_counts_min_neg", 1)
+    try:
+        con = make_engine(model, E, R, D, n, 0, params=params)
+        dev = torch.from_numpy(np.stack([bh, bt, br]).astype(np.int32)).cuda()
+        con.forward_backward(dev, B, B, B * n)
+        torch.cuda.synchronize()
+        assert abs(float(con._loss.item()) - loss_o) <= RTOL * abs(loss_o)
+        g_g = con.get_gradients()
+        for k in g_o:
+            assert relerr(g_g[k], g_o[k]) < RTOL, (k, relerr(g_g[k], g_o[k]))
+    finally:
+        L.kge_set_option(b"float_records_min", 1 << 16)
+        L.kge_set_option(b"pair_counts_min_neg", 4)
