@@ -181,9 +181,11 @@ __global__ __launch_bounds__(256, 2) void pair_emit_kernel(FbArgs a) {
             }
         }
         // ---- negatives ----
-        s16x2 Ah_lo[Q], Ah_hi[Q], At_lo[Q], At_hi[Q], Ar_lo[Q], Ar_hi[Q];
+        // integer sums of the signs reaching the positive's h^n (-s per active new-tail pair) and t^n (+s per active new-head pair);
+        // the sum reaching r^ (-s per active pair of either kind) is their difference Ah - At and is not kept
+        s16x2 Ah_lo[Q], Ah_hi[Q], At_lo[Q], At_hi[Q];
 #pragma unroll
-        for (int q = 0; q < Q; q++) { Ah_lo[q] = 0; Ah_hi[q] = 0; At_lo[q] = 0; At_hi[q] = 0; Ar_lo[q] = 0; Ar_hi[q] = 0; }
+        for (int q = 0; q < Q; q++) { Ah_lo[q] = 0; Ah_hi[q] = 0; At_lo[q] = 0; At_hi[q] = 0; }
         float acw[E];       // relation-context gradient, vector part: sum of c1*x + c2*g
         float acw_s = 0.f;  // TransH: coefficient of w^ ; TransD: coefficient of r_p
 #pragma unroll
@@ -192,19 +194,21 @@ __global__ __launch_bounds__(256, 2) void pair_emit_kernel(FbArgs a) {
         // the relation-context gradient of one entity side with upstream gradient unit*g (g integer valued):
         //   TransH: acw -= d x + a gxp     TransD: acw += a gxp     with gxp = inv (G - nrm <nrm, G>), nrm = inv xp
         // written on x, g and the context vector so that neither gxp nor nrm is materialised
-        auto context_grad = [&](const float (&x)[E], const float (&xp)[E], const float (&gf)[E], float aa, float inv, bool uc) {
+        // (the upstream gradient is unit * kf * gf: gf the sign vector as floats, kf = -1 / +1 / 0 for a negative, 1 for the sums)
+        auto context_grad = [&](const float (&x)[E], const float (&xp)[E], const float (&gf)[E], float kf, float aa, float inv, bool uc) {
+            const float uk = a.unit * kf;
             float al = dot16<E>(xp, gf);
-            al = uc ? inv * a.unit * al : 0.f;            // <nrm, G>
+            al = uc ? inv * uk * al : 0.f;                // <nrm, G>
             const float i2a = inv * inv * al;             // gxp = (inv unit) g - i2a xp
             if constexpr (MODEL == KGE_TRANSH) {
                 const float qq = dot16<E>(cw, gf);
-                const float d = inv * a.unit * qq - i2a * (aa * (1.0f - ww));   // gxp . w^   (xp . w^ = a (1 - |w^|^2))
-                const float c1 = d - aa * i2a, c2 = aa * inv * a.unit;          // d x + a gxp = c1 x + c2 g + (a^2 i2a) w^
+                const float d = inv * uk * qq - i2a * (aa * (1.0f - ww));       // gxp . w^   (xp . w^ = a (1 - |w^|^2))
+                const float c1 = d - aa * i2a, c2 = aa * inv * uk;              // d x + a gxp = c1 x + c2 g + (a^2 i2a) w^
 #pragma unroll
                 for (int e = 0; e < E; e++) acw[e] += c1 * x[e] + c2 * gf[e];
                 acw_s += aa * aa * i2a;
             } else {
-                const float c1 = -aa * i2a, c2 = aa * inv * a.unit;             // a gxp = c2 g - a i2a (x + a r_p)
+                const float c1 = -aa * i2a, c2 = aa * inv * uk;                 // a gxp = c2 g - a i2a (x + a r_p)
 #pragma unroll
                 for (int e = 0; e < E; e++) acw[e] += c1 * x[e] + c2 * gf[e];
                 acw_s += -aa * aa * i2a;
@@ -246,20 +250,17 @@ __global__ __launch_bounds__(256, 2) void pair_emit_kernel(FbArgs a) {
                 {
                     const s16x2 kh = pack16(code == 1 && act ? -1 : 0, code == 1 && act ? -1 : 0);   // kept h of a new-tail pair gets -s
                     const s16x2 kt = pack16(code == 0 && act ? 1 : 0, code == 0 && act ? 1 : 0);     // kept t of a new-head pair gets +s
-                    const s16x2 kr = pack16(act ? -1 : 0, act ? -1 : 0);                             // r^ gets -s either way
                     const s16x2 kxx = pack16(kx, kx);
                     uint32_t rec[Q];
 #pragma unroll
                     for (int q = 0; q < Q; q++) {
                         const int s0 = sign_of_bits(ev[4 * q]), s1 = sign_of_bits(ev[4 * q + 1]);
                         const int s2 = sign_of_bits(ev[4 * q + 2]), s3 = sign_of_bits(ev[4 * q + 3]);
-                        gf[4 * q] = (float)(s0 * kx); gf[4 * q + 1] = (float)(s1 * kx);
-                        gf[4 * q + 2] = (float)(s2 * kx); gf[4 * q + 3] = (float)(s3 * kx);
+                        gf[4 * q] = (float)s0; gf[4 * q + 1] = (float)s1; gf[4 * q + 2] = (float)s2; gf[4 * q + 3] = (float)s3;
                         const s16x2 s_lo = pack16(s0, s1), s_hi = pack16(s2, s3);
                         rec[q] = bytes_of(s_lo * kxx, s_hi * kxx);
                         Ah_lo[q] += s_lo * kh; Ah_hi[q] += s_hi * kh;
                         At_lo[q] += s_lo * kt; At_hi[q] += s_hi * kt;
-                        Ar_lo[q] += s_lo * kr; Ar_hi[q] += s_hi * kr;
                     }
                     if (act) {
                         uint32_t *pr = a.rec + ((long long)(2 + k0 + kk) * a.n_pos + b) * (PT * Q);
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void pair_emit_kernel(FbArgs a) {
                         for (int q = 0; q < Q; q++) pr[lane + PT * q] = rec[q];
                     }
                 }
-                context_grad(x, xp, gf, aa, inv, uc);   // (all zero when inactive: g = 0)
+                context_grad(x, xp, gf, (float)kx, aa, inv, uc);   // (all zero when inactive: kx = 0)
                 if (lane == kk) my_dst = act ? (int)((long long)row * R + r) : -1;
             };
             // Two row buffers used alternately (the loop is unrolled by two, so no register moves): while a negative is scored
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void pair_emit_kernel(FbArgs a) {
                 const s16x2 v_lo = pack16(sp[0], sp[1]) * c2, v_hi = pack16(sp[2], sp[3]) * c2;
                 const s16x2 h_lo = Ah_lo[q] + v_lo, h_hi = Ah_hi[q] + v_hi;
                 const s16x2 t_lo = At_lo[q] - v_lo, t_hi = At_hi[q] - v_hi;
-                const s16x2 r_lo = Ar_lo[q] + v_lo, r_hi = Ar_hi[q] + v_hi;
+                const s16x2 r_lo = Ah_lo[q] - At_lo[q] + v_lo, r_hi = Ah_hi[q] - At_hi[q] + v_hi;
                 rech[q] = bytes_of(h_lo, h_hi); rect[q] = bytes_of(t_lo, t_hi);
                 gh[4 * q] = (float)h_lo.x; gh[4 * q + 1] = (float)h_lo.y; gh[4 * q + 2] = (float)h_hi.x; gh[4 * q + 3] = (float)h_hi.y;
                 gt[4 * q] = (float)t_lo.x; gt[4 * q + 1] = (float)t_lo.y; gt[4 * q + 2] = (float)t_hi.x; gt[4 * q + 3] = (float)t_hi.y;
@@ -341,8 +342,8 @@ __global__ __launch_bounds__(256, 2) void pair_emit_kernel(FbArgs a) {
                 if (lane == 0) a.dst[b] = (int)((long long)h * R + r);
                 if (lane == 1) a.dst[a.n_pos + b] = (int)((long long)t * R + r);
             }
-            context_grad(xh, xph, gh, ah, ih, uch);
-            context_grad(xt, xpt, gt, at, it, uct);
+            context_grad(xh, xph, gh, 1.0f, ah, ih, uch);
+            context_grad(xt, xpt, gt, 1.0f, at, it, uct);
             // hub copy of the relation-side tables this group adds into
             const long long hub = a.copies_rel ? b % a.hub_k : 0;
             float *grel = a.copies_rel ? a.copies_rel + hub * R * D : a.g_rel;
