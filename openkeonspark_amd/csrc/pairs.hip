@@ -51,12 +51,19 @@ __device__ __forceinline__ void load_row(const float *__restrict__ tab, long lon
     }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// dot product over the team: two running sums (even / odd elements) so that the products go through v_pk_fma_f32 -- half the
+// instructions of a scalar fma chain, and a third of the packed-multiply + scalar-add form the compiler chose for one sum
 template <int E>
 __device__ __forceinline__ float dot16(const float (&x)[E], const float (&y)[E]) {
-    float s = 0.f;
+    f32x2 s = {0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < E; e++) s += x[e] * y[e];
-    return team_sum<PT>(s);
+    for (int e = 0; e < E; e += 2) {
+        const f32x2 xv = {x[e], x[e + 1]}, yv = {y[e], y[e + 1]};
+        s = __builtin_elementwise_fma(xv, yv, s);
+    }
+    return team_sum<PT>(s.x + s.y);
 }
 
 // Atomic add of a row held in the natural layout (lane l: float4 chunks l, l+16, ...).  Memory-side atomics are served per
