@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--gather-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: the NON-PARITY fast mode (rows gathered from bf16 shadows of the fp32 tables); a second, separately "
                          "labelled line -- the fp32 default stays the headline")
+    ap.add_argument("--prefetch-sampling", choices=["auto", "on", "off"], default="auto",
+                    help="batch i+1 sampled on a side stream behind the emit kernel of step i (Config.prefetch_sampling; "
+                         "bit-identical batches).  auto = the Config default")
     args = ap.parse_args()
 
     import numpy as np
@@ -164,6 +167,8 @@ def main():
     con.set_alpha(0.001)
     con.set_opt_method("Adam")
     con.gather_dtype = args.gather_dtype
+    if args.prefetch_sampling != "auto":
+        con.prefetch_sampling = args.prefetch_sampling == "on"
     con.init()
     con.set_model_and_session(TransE)
     if use_dist:

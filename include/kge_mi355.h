@@ -115,6 +115,7 @@ const char *kge_version(void);
  *   "float_records":     1 (default) = kge_forward_backward stores TransE/H/D gradient rows as records and sums
  *                        them by destination after a sort; 0 = fp32 atomic adds straight into the accumulators
  *   "float_records_min": smallest number of gradient rows per step that takes the record path (default 65536: measured cross-over, tools/sweep_paths.py)
+ *   "record_emit_event": 1 = record an event behind every TransE emit launch (kge_stream_wait_emit); default 0
  *   "pair_counts":       1 (default) = TransH / TransD steps of at least float_records_min entity-side rows (widths that are
  *                        multiples of 4 up to 256, at most 63 negatives, ent_total*rel_total below 2^31) take the
  *                        pair-count path: int8 sign records keyed by (entity, relation), the backward applied once per pair
@@ -210,6 +211,12 @@ int kge_forward_backward(const kge_model_desc *m, const float *const tables[KGE_
                          const int32_t *d_h, const int32_t *d_t, const int32_t *d_r,
                          INT n_pos, INT n_neg, INT stride, INT denom,
                          float *const grads[KGE_MAX_TABLES], float *d_loss, void *stream);
+
+/* Makes `stream` wait for the most recent launch of the TransE emit kernel (option "record_emit_event" = 1 records an event
+ * behind every such launch).  Config.prefetch_sampling uses it to start the next batch's sampler on a side stream as soon as the
+ * emit kernel -- the one bandwidth-bound kernel of the step -- has finished, so that it runs beside the small latency-bound
+ * kernels that follow (bucketing, segmented sum, apply).  No emit kernel launched yet: returns at once. */
+int kge_stream_wait_emit(void *stream);
 
 /* The same call for a batch the caller KNOWS to be sampler-shaped -- what kge_sampling_device / `sampling` produce
  * (Base.cpp:109-139): every negative differs from its positive in exactly one entity slot, or (negative_rel) in the relation.

@@ -282,17 +282,19 @@ class Config(object):
         self._dev_batch2 = None
         self._side_stream = None
         self._prefetched = None
-        # None = automatic: off at 1 GPU (measured: the sampler then competes with segsum/apply for the same CUs),
-        # on in data-parallel runs, where batch i+1 is drawn while step i's gradient all-reduce waits on the wire
-        self.prefetch_sampling = getattr(self, "prefetch_sampling", None)
-        if self.prefetch_sampling is None and self.world_size > 1:
-            self.prefetch_sampling = True
         self.global_step = 0
         self._sparse_buf = None
         # TransE steps with fewer gradient rows than this take the single fused fp32-atomic kernel (launch-bound
         # regime, tools/sweep_paths.py); 0 = always the exact, run-to-run reproducible count pipeline
         self.counts_min_records = int(getattr(self, "counts_min_records",
                                               os.environ.get("KGE_COUNTS_MIN_RECORDS", 1 << 16)))
+        # None = automatic: on in data-parallel runs (batch i+1 is drawn while step i's gradient exchange waits on the wire) and,
+        # at 1 GPU, on the sign-count path, where the sampler starts right behind the emit kernel and runs beside the small
+        # kernels after it (measured +4 %); off on the other 1-GPU paths (there it only competes with the step's own kernels)
+        self.prefetch_sampling = getattr(self, "prefetch_sampling", None)
+        self._prefetch_auto = self.prefetch_sampling is None      # (init_distributed decides again once the world size is known)
+        if self._prefetch_auto:
+            self.prefetch_sampling = self._prefetch_default()
         if self.use_counts and not self.sparse_rows:
             self._counts = torch.zeros((self.entTotal + self.relTotal, self.hidden_size), dtype=torch.int32,
                                        device=self.device)
@@ -320,8 +322,14 @@ class Config(object):
         self.world_size = dist.get_world_size(process_group)
         if self.trainModel is not None:
             self._setup_partition()
-        if getattr(self, "prefetch_sampling", None) is None and self.world_size > 1:
-            self.prefetch_sampling = True
+        if getattr(self, "_prefetch_auto", getattr(self, "prefetch_sampling", None) is None):
+            self.prefetch_sampling = self._prefetch_default()
+
+    def _prefetch_default(self):
+        n_neg = self.negative_ent + self.negative_rel
+        counts_path = bool(getattr(self, "use_counts", False)) and not getattr(self, "sparse_rows", False) and \
+            self.batch_size * (3 + n_neg) >= int(getattr(self, "counts_min_records", 1 << 16)) * self.world_size
+        return bool(self.world_size > 1 or counts_path)
 
     def _setup_partition(self):
         from .parallel import thread_range
@@ -467,6 +475,7 @@ class Config(object):
             self._side_stream = torch.cuda.Stream()
             self._slot = 0
             self._prefetched = None
+            self.lib.kge_set_option(b"record_emit_event", 1)
         if self._prefetched is None:
             dev, n_pos = self.sample_device(self._slot)
         else:
@@ -474,14 +483,23 @@ class Config(object):
             main.wait_event(ev)
         return dev, n_pos
 
-    def _prefetch_next_batch(self):
+    def _prefetch_next_batch(self, behind_emit=False):
+        """behind_emit=True (the sign-count path): the side stream waits for THIS step's emit kernel only -- the one
+        bandwidth-bound kernel of the step, which a concurrent sampler would slow down by what it takes -- and the sampler
+        then runs beside the small latency-bound kernels after it (bucketing, segmented sum, apply).  The other slot's last
+        readers (the previous step's kernels) are older than that emit kernel."""
         import torch
         main = torch.cuda.current_stream()
-        done = torch.cuda.Event()
-        done.record(main)                      # the consumers of the OTHER slot (previous step) were enqueued before this
+        done = None
+        if not behind_emit:
+            done = torch.cuda.Event()
+            done.record(main)                  # the consumers of the OTHER slot (previous step) were enqueued before this
         self._slot ^= 1
         with torch.cuda.stream(self._side_stream):
-            self._side_stream.wait_event(done)  # slot reuse: its last reader is older than `done`
+            if behind_emit:
+                _lib.check(self.lib.kge_stream_wait_emit(ctypes.c_void_p(self._side_stream.cuda_stream)), self.lib)
+            else:
+                self._side_stream.wait_event(done)  # slot reuse: its last reader is older than `done`
             dev, n_pos = self.sample_device(self._slot)
             ev = torch.cuda.Event()
             ev.record(self._side_stream)
@@ -577,7 +595,7 @@ class Config(object):
         elif self.use_counts and big:
             self.forward_counts(dev, n_pos, stride, denom, sampler_shaped=batch_h is None)
             if batch_h is None and self.prefetch_sampling:
-                self._prefetch_next_batch()
+                self._prefetch_next_batch(behind_emit=True)
             if self.world_size > 1:
                 # int32 SUM is exact: rank g receives the summed counts of ITS rows, updates them, and the updated rows go round
                 from .parallel import reduce_scatter_sum, allreduce_sum, all_gather_chunks

@@ -70,6 +70,7 @@ def _declare(L):
     L.kge_table_shape.argtypes = [ctypes.POINTER(ModelDesc), ctypes.c_int, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     tabs = ctypes.POINTER(vp)
     L.kge_forward_backward.argtypes = [ctypes.POINTER(ModelDesc), tabs, vp, vp, vp, i64, i64, i64, i64, tabs, vp, vp]
+    L.kge_stream_wait_emit.argtypes = [vp]
     L.kge_forward_backward_sampled.argtypes = [ctypes.POINTER(ModelDesc), tabs, vp, vp, vp, i64, i64, i64, i64, tabs, vp, vp]
     L.kge_sgd_update.argtypes = [vp, vp, i64, f32, vp]
     L.kge_adam_update.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp]

@@ -225,6 +225,7 @@ int kge_set_option(const char *name, INT value) {
     if (n == "index_device_min") { engine().index_device_min = value; return KGE_OK; }
     if (n == "hub_copies") { engine().hub_copies = value != 0; return KGE_OK; }
     if (n == "pair_counts") { engine().pair_counts = value != 0; return KGE_OK; }
+    if (n == "record_emit_event") { engine().record_emit_event = value != 0; return KGE_OK; }
     if (n == "transr_lean") { engine().transr_lean = value != 0; return KGE_OK; }
     if (n == "pair_counts_min_neg") { engine().pair_counts_min_neg = (int)value; return KGE_OK; }
     if (n == "lp_v1") { engine().lp_v1 = value != 0; return KGE_OK; }
@@ -355,6 +356,12 @@ int kge_forward_backward(const kge_model_desc *m, const float *const tables[KGE_
                          float *const grads[KGE_MAX_TABLES], float *d_loss, void *stream) {
     if (!m || !tables || !grads || !d_loss) return fail(KGE_ERR_BAD_ARG, "kge_forward_backward: null argument");
     return launch_forward_backward(*m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, grads, d_loss, (hipStream_t)stream, false);
+}
+
+int kge_stream_wait_emit(void *stream) {
+    Engine &e = engine();
+    if (!e.emit_done) return KGE_OK;   // no emit kernel launched yet (or recording off): nothing to wait for
+    return hip_check(hipStreamWaitEvent((hipStream_t)stream, e.emit_done, 0), "wait for the emit kernel");
 }
 
 int kge_forward_backward_sampled(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES], const int32_t *d_h,

@@ -524,6 +524,10 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
         else if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         if (timed) { (void)hipEventRecord(eng.ev_emit1[slot], stream); eng.emit_launches++; }
+        if (eng.record_emit_event) {   // lets another stream start behind THIS kernel (the next batch's sampler, Config.prefetch_sampling)
+            if (!eng.emit_done) (void)hipEventCreateWithFlags(&eng.emit_done, hipEventDisableTiming);
+            (void)hipEventRecord(eng.emit_done, stream);
+        }
     } else
         hipLaunchKernelGGL((transe_emit_kernel<L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
     // groups with non sampler-shaped negatives: exact fp32 path into the residual accumulators
