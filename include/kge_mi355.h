@@ -212,11 +212,14 @@ int kge_forward_backward(const kge_model_desc *m, const float *const tables[KGE_
                          INT n_pos, INT n_neg, INT stride, INT denom,
                          float *const grads[KGE_MAX_TABLES], float *d_loss, void *stream);
 
-/* Makes `stream` wait for the most recent launch of the TransE emit kernel (option "record_emit_event" = 1 records an event
+/* Makes `stream` wait for the most recent launch of the TransE emit kernel (or of the pair-count path's emit kernel) (option "record_emit_event" = 1 records an event
  * behind every such launch).  Config.prefetch_sampling uses it to start the next batch's sampler on a side stream as soon as the
  * emit kernel -- the one bandwidth-bound kernel of the step -- has finished, so that it runs beside the small latency-bound
  * kernels that follow (bucketing, segmented sum, apply).  No emit kernel launched yet: returns at once. */
 int kge_stream_wait_emit(void *stream);
+/* 1 when kge_forward_backward on a step of this shape takes the TransH / TransD pair-count path (whose emit kernel also records
+ * the event above), else 0 */
+int kge_pair_path_active(const kge_model_desc *m, INT n_pos, INT n_neg);
 
 /* The same call for a batch the caller KNOWS to be sampler-shaped -- what kge_sampling_device / `sampling` produce
  * (Base.cpp:109-139): every negative differs from its positive in exactly one entity slot, or (negative_rel) in the relation.

@@ -329,7 +329,9 @@ class Config(object):
         n_neg = self.negative_ent + self.negative_rel
         counts_path = bool(getattr(self, "use_counts", False)) and not getattr(self, "sparse_rows", False) and \
             self.batch_size * (3 + n_neg) >= int(getattr(self, "counts_min_records", 1 << 16)) * self.world_size
-        return bool(self.world_size > 1 or counts_path)
+        pair_path = getattr(self, "_desc", None) is not None and \
+            bool(self.lib.kge_pair_path_active(ctypes.byref(self._desc), max(self._n_local, 1) if hasattr(self, "_n_local") else self.batch_size, n_neg))
+        return bool(self.world_size > 1 or counts_path or pair_path)
 
     def _setup_partition(self):
         from .parallel import thread_range
@@ -610,7 +612,7 @@ class Config(object):
         else:
             self.forward_backward(dev, n_pos, stride, denom, sampler_shaped=batch_h is None)
             if batch_h is None and self.prefetch_sampling:
-                self._prefetch_next_batch()
+                self._prefetch_next_batch(behind_emit=bool(self.lib.kge_pair_path_active(ctypes.byref(self._desc), n_pos, n_neg)))
             if self.world_size > 1:
                 from .parallel import reduce_scatter_sum, allreduce_sum, all_gather_chunks
                 reduce_scatter_sum(self._grads_own, self._flat_g, self._pg)

@@ -358,6 +358,8 @@ int kge_forward_backward(const kge_model_desc *m, const float *const tables[KGE_
     return launch_forward_backward(*m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, grads, d_loss, (hipStream_t)stream, false);
 }
 
+int kge_pair_path_active(const kge_model_desc *m, INT n_pos, INT n_neg) { return m && pair_path_active(*m, n_pos, n_neg) ? 1 : 0; }
+
 int kge_stream_wait_emit(void *stream) {
     Engine &e = engine();
     if (!e.emit_done) return KGE_OK;   // no emit kernel launched yet (or recording off): nothing to wait for

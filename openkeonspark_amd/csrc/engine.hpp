@@ -114,6 +114,7 @@ struct FloatRowSpace {   // virtual row space of models.hip's FbArgs::frec recor
     long long hub_base, hub_rows;   // copies of { rel [R] | auxr [R] } from hub_base on, hub_rows rows per copy
     long long rows;             // total virtual rows
 };
+bool pair_path_active(const kge_model_desc &m, int64_t n_pos, int64_t n_neg);
 int float_records_workspace(int64_t M, int D, float *&rec, int32_t *&dst);
 int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t stream);
 

@@ -488,6 +488,14 @@ __global__ __launch_bounds__(256) void row_inv_norm_bf16_kernel(const uint16_t *
     }
 }
 
+// lets another stream start behind the emit kernel just launched (the next batch's sampler, Config.prefetch_sampling)
+static void record_emit_done(hipStream_t stream) {
+    Engine &eng = engine();
+    if (!eng.record_emit_event) return;
+    if (!eng.emit_done) (void)hipEventCreateWithFlags(&eng.emit_done, hipEventDisableTiming);
+    (void)hipEventRecord(eng.emit_done, stream);
+}
+
 constexpr int kDeferBlocks = 128;
 
 template <int L, int C>
@@ -524,10 +532,7 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
         else if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         if (timed) { (void)hipEventRecord(eng.ev_emit1[slot], stream); eng.emit_launches++; }
-        if (eng.record_emit_event) {   // lets another stream start behind THIS kernel (the next batch's sampler, Config.prefetch_sampling)
-            if (!eng.emit_done) (void)hipEventCreateWithFlags(&eng.emit_done, hipEventDisableTiming);
-            (void)hipEventRecord(eng.emit_done, stream);
-        }
+        record_emit_done(stream);
     } else
         hipLaunchKernelGGL((transe_emit_kernel<L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
     // groups with non sampler-shaped negatives: exact fp32 path into the residual accumulators
@@ -758,6 +763,14 @@ void launch_pair_emit(int model, const FbArgs &a, hipStream_t stream);
 int pair_records_workspace(int64_t M, int rd, uint32_t *&rec, int32_t *&dst);
 int pair_records_reduce(int model, int64_t M, int D, int rd, int64_t ent_total, int64_t rel_total, const float *const tables[4],
                         float *const grads[4], float unit, hipStream_t stream);
+
+// does a step of this shape take the pair-count path?  (also behind kge_pair_path_active: Config places its sampler prefetch by it)
+bool pair_path_active(const kge_model_desc &m, int64_t n_pos, int64_t n_neg) {
+    Engine &e = engine();
+    return e.pair_counts && m.ent_dim == m.rel_dim && n_neg >= e.pair_counts_min_neg && pair_counts_shape_ok(m.model, m.ent_dim, n_neg) &&
+           pair_keys_sortable(m.ent_total, m.rel_total) && n_pos * (2 + n_neg) >= e.float_records_min &&
+           n_pos * (2 + n_neg) < (int64_t(1) << 31);
+}
 
 // the exact fp32 kernel over the groups an emit kernel deferred (a.group_list), partial losses behind the emit kernel's
 template <int MODEL>
@@ -1015,8 +1028,7 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
     a.P = nullptr; a.GP = nullptr; a.negative_rel = m.negative_rel;
     int rc;
     // Pair-count path (TransH / TransD): int8 sign records keyed by (entity, relation), the backward applied once per pair
-    if (e.pair_counts && n_neg >= e.pair_counts_min_neg && pair_counts_shape_ok(m.model, a.D, n_neg) && pair_keys_sortable(m.ent_total, m.rel_total) &&
-        n_pos * (2 + n_neg) >= e.float_records_min && n_pos * (2 + n_neg) < (int64_t(1) << 31)) {
+    if (pair_path_active(m, n_pos, n_neg)) {
         const int64_t M = n_pos * (2 + n_neg);
         const int rd = pair_record_dwords(a.D);
         if ((rc = pair_records_workspace(M, rd, a.rec, a.dst))) return rc;
@@ -1027,6 +1039,7 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
             // the caller vouches for the batch: no deferral list, the emit kernel's last workgroup writes the loss
             a.loss_out = d_loss; a.loss_ticket = e.dev.loss_ticket;
             launch_pair_emit(m.model, a, stream);
+            record_emit_done(stream);
         } else {
             if (n_pos > g_defer_cap) {
                 if (g_defer_list) (void)hipFree(g_defer_list);
@@ -1038,6 +1051,7 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
             if ((rc = hip_check(hipMemsetAsync(g_defer_count, 0, sizeof(int32_t), stream), "zero deferred count"))) return rc;
             a.group_list = g_defer_list; a.group_count = g_defer_count;
             launch_pair_emit(m.model, a, stream);
+            record_emit_done(stream);
             // groups with negatives that are not sampler-shaped: the exact fp32 kernel (atomic adds), its partial losses behind the emit's
             FbArgs d = a;
             d.loss_partials = a.loss_partials + pair_emit_blocks(n_pos);
