@@ -7,6 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 mkdir -p $GRAFT_REPO_ROOT/$out
 cd $GRAFT_REPO_ROOT
 python3 bench.py > $out/bench_default.log 2>&1; grep -a "^{" $out/bench_default.log | tail -1 > $out/bench_line_default.json
+python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline > $out/bench_steps50.log 2>&1; grep -a "^{" $out/bench_steps50.log | tail -1 > $out/bench_line_steps50.json
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_steps20.log 2>&1; grep -a "^{" $out/bench_steps20.log | tail -1 > $out/bench_line_steps20.json
 rocprofv3 --kernel-trace --stats -d $out/kt -o r -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/kt.log 2>&1
 python3 tools/rocpd_stats.py $out/kt/r_results.db $out/kernel_stats_bench.csv
