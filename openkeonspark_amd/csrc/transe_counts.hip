@@ -963,6 +963,13 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
         int32_t *Sp = a.S + (i - a.row_lo) * a.D;
         float *rp = SPARSE ? nullptr : rt + row * a.D;
         float s[C], rs[C];
+        float x[C], g[C], m_old[C], v_old[C];
+        // TF1 Adam moves EVERY row: its parameter and moment rows are requested together with the counts, not after the
+        // "touched?" reduction (one memory round trip per row instead of two)
+        const bool every_row = !SPARSE && a.adam;
+        if (every_row) {
+            tm.load(table, row, x); tm.load(mt, row, m_old); tm.load(vt, row, v_old);
+        }
         float touched = 0.f;
 #pragma unroll
         for (int c = 0; c < C; c++) {
@@ -974,8 +981,7 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
         }
         touched = team_sum<L>(touched);
         if (touched == 0.f && !a.adam) continue;  // SGD leaves untouched rows alone; TF1 Adam moves every row
-        float x[C], g[C];
-        tm.load(table, row, x);
+        if (!every_row) tm.load(table, row, x);
         if (touched != 0.f) {
             float xn[C], inv; bool uc;
             tm.normalize(x, xn, inv, uc);
@@ -994,7 +1000,7 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
             if (e >= a.D) continue;
             if (!SPARSE && a.adam) {
                 float *mp = mt + row * a.D + e, *vp = vt + row * a.D + e;
-                float mi = __fmul_rn(*mp, a.b1), vi = __fmul_rn(*vp, a.b2);
+                float mi = __fmul_rn(m_old[c], a.b1), vi = __fmul_rn(v_old[c], a.b2);
                 if (g[c] != 0.f) {
                     mi = __fadd_rn(mi, __fmul_rn(g[c], 1.0f - a.b1));
                     vi = __fadd_rn(vi, __fmul_rn(__fmul_rn(g[c], g[c]), 1.0f - a.b2));
