@@ -31,11 +31,6 @@ namespace {
 
 constexpr int PT = 16;   // lanes per team
 
-template <int Q>
-struct Rows {   // a row as this lane sees it: Q float4 chunks
-    float v[4 * Q];
-};
-
 // Row gather in the natural layout.  Q = ceil(D / 64), so every lane's chunks q < Q-1 exist; only the last chunk can lie
 // past the row's end.  It is loaded from a clamped address and zeroed by a select: a conditional load would compile into a
 // branch around it with its own wait, i.e. one memory latency per chunk instead of one per row.
