@@ -760,7 +760,7 @@ bool pair_keys_sortable(int64_t ent_total, int64_t rel_total);
 long long pair_emit_blocks(int64_t n_pos);
 int pair_record_dwords(int D);
 void launch_pair_emit(int model, const FbArgs &a, hipStream_t stream);
-int pair_records_workspace(int64_t M, int rd, uint32_t *&rec, int32_t *&dst);
+int pair_records_workspace(int64_t M, int rd, uint32_t *&rec, int32_t *&dst, float2 *&aux);
 int pair_records_reduce(int model, int64_t M, int D, int rd, int64_t ent_total, int64_t rel_total, const float *const tables[4],
                         float *const grads[4], float unit, hipStream_t stream);
 
@@ -1031,7 +1031,7 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
     if (pair_path_active(m, n_pos, n_neg)) {
         const int64_t M = n_pos * (2 + n_neg);
         const int rd = pair_record_dwords(a.D);
-        if ((rc = pair_records_workspace(M, rd, a.rec, a.dst))) return rc;
+        if ((rc = pair_records_workspace(M, rd, a.rec, a.dst, a.pair_aux))) return rc;
         a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total;
         if ((rc = attach_hub_copies(m, n_pos, a))) return rc;
         guard_loss_stream(stream);

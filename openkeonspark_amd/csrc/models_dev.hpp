@@ -44,6 +44,9 @@ struct FbArgs {
     // atomic path on a KG with few relations (WN18RR: 11): thousands of groups per step add into the same R rows and
     // same-address atomics serialise; group b adds into copy b % hub_k of [hub_k][R][D] buffers, folded afterwards
     float *copies_rel, *copies_auxr;
+    // pair-count path (pairs.hip): per record the projection coefficient a and 1/|projected| of its (entity, relation) pair
+    // (negative 1/|.| = the norm was clipped), so that the per-pair backward need not recompute them
+    float2 *pair_aux;
 };
 
 int ensure_loss_buffers();

@@ -265,9 +265,11 @@ __global__ __launch_bounds__(256, 2) void pair_emit_kernel(FbArgs a) {
                         At_lo[q] += s_lo * kt; At_hi[q] += s_hi * kt;
                     }
                     if (act) {
-                        uint32_t *pr = a.rec + ((long long)(2 + k0 + kk) * a.n_pos + b) * (PT * Q);
+                        const long long m = (long long)(2 + k0 + kk) * a.n_pos + b;
+                        uint32_t *pr = a.rec + m * (PT * Q);
 #pragma unroll
                         for (int q = 0; q < Q; q++) pr[lane + PT * q] = rec[q];
+                        if (lane == 0) a.pair_aux[m] = make_float2(aa, uc ? inv : -inv);
                     }
                 }
                 context_grad(x, xp, gf, (float)kx, aa, inv, uc);   // (all zero when inactive: kx = 0)
@@ -341,8 +343,8 @@ __global__ __launch_bounds__(256, 2) void pair_emit_kernel(FbArgs a) {
                 uint32_t *ph = a.rec + b * (long long)(PT * Q), *pt = a.rec + (a.n_pos + b) * (long long)(PT * Q);
 #pragma unroll
                 for (int q = 0; q < Q; q++) { ph[lane + PT * q] = rech[q]; pt[lane + PT * q] = rect[q]; }
-                if (lane == 0) a.dst[b] = (int)((long long)h * R + r);
-                if (lane == 1) a.dst[a.n_pos + b] = (int)((long long)t * R + r);
+                if (lane == 0) { a.dst[b] = (int)((long long)h * R + r); a.pair_aux[b] = make_float2(ah, uch ? ih : -ih); }
+                if (lane == 1) { a.dst[a.n_pos + b] = (int)((long long)t * R + r); a.pair_aux[a.n_pos + b] = make_float2(at, uct ? it : -it); }
             }
             context_grad(xh, xph, gh, 1.0f, ah, ih, uch);
             context_grad(xt, xpt, gt, 1.0f, at, it, uct);

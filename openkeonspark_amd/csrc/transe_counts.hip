@@ -44,6 +44,8 @@ struct CtWork {
     int32_t *n_valid = nullptr;
     int32_t *tile_hist = nullptr, *bucket_start = nullptr;   // LDS-bucket path: bucket totals + cursors, bucket starts
     int32_t *pairs = nullptr;                                  // [2*cap] (record id, destination) grouped by bucket
+    float2 *pair_aux = nullptr;                                // [cap] pair-count path: (a, +-1/|projected|) per record
+    int64_t pair_aux_cap = 0;
     int64_t cap_hist = 0;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0, rec_elems = 0;
@@ -624,6 +626,7 @@ __global__ __launch_bounds__(256) void segsum_f32_kernel(const float *__restrict
 struct PairRed {
     const float *ent, *ctx, *auxe;    // ent_embeddings; per relation: TransH the NORMALISED normal vector (ctx_normalize_kernel), TransD rel_transfer; ent_transfer (TransD)
     float *g_ent, *g_auxe;
+    const float2 *aux;                // per record: (a, +-1/|projected|) of its pair, from the emit kernel's forward
     int D, R, RD;                     // embedding width, relations, dwords per record
     unsigned magic;                   // ceil(2^32 / R): key / R by multiply-high (+ fix-up)
     float unit;
@@ -689,7 +692,7 @@ __global__ __launch_bounds__(256) void segsum_pairs_kernel(const uint32_t *__res
     };
     // one pair = one run of equal keys: [lo, hi) inside the chunk.  Its rows and first W records are REQUESTED one pair ahead
     // of the arithmetic (the dependent gathers, not the arithmetic, bounded the first version of this kernel).
-    struct Pair { int lo, hi, row, rel; float4 x, cw, xa; uint32_t w[W]; };
+    struct Pair { int lo, hi, row, rel; float4 x, cw, xa; float2 ai; uint32_t w[W]; };
     auto request = [&](Pair &q, int lo, int hi) {
         q.lo = lo; q.hi = hi;
         const unsigned key = (unsigned)__builtin_amdgcn_readlane(kl, lo);
@@ -704,6 +707,7 @@ __global__ __launch_bounds__(256) void segsum_pairs_kernel(const uint32_t *__res
         for (int u = 0; u < W; u++) {
             const long long id = __builtin_amdgcn_readlane(idl, min(lo + u, hi - 1));
             q.w[u] = rec[id * pr.RD + (valid ? lane : 0)];
+            if (u == 0) q.ai = pr.aux[id];   // every record of a pair carries the same two numbers
         }
     };
     auto next_run = [&](int &lo, int &hi) {
@@ -738,21 +742,20 @@ __global__ __launch_bounds__(256) void segsum_pairs_kernel(const uint32_t *__res
         // ---- the pair's entity-row gradient (side_backward of models_dev.hpp applied once to the summed signs) ----
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 x = valid ? cur.x : z, cw = valid ? cur.cw : z;
+        // the projection coefficient and 1/|projected| of this (entity, relation) pair come from the emit kernel's forward
+        // (two reductions and a rsqrt per pair less; they are the very numbers the scores were computed with)
         float4 xa = z, xp;
-        float a;
+        const float a = cur.ai.x;
+        const bool uc = cur.ai.y > 0.f;
+        const float inv = fabsf(cur.ai.y);
         if constexpr (MODEL == KGE_TRANSH) {
-            a = team_sum<L>(dot4(x, cw));
             xp = make_float4(x.x - a * cw.x, x.y - a * cw.y, x.z - a * cw.z, x.w - a * cw.w);
         } else {
             xa = valid ? cur.xa : z;
-            a = team_sum<L>(dot4(x, xa));
             xp = make_float4(x.x + a * cw.x, x.y + a * cw.y, x.z + a * cw.z, x.w + a * cw.w);
         }
         const float4 S = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
-        float ss = dot4(xp, xp), dp = dot4(xp, S);
-        ss = team_sum<L>(ss); dp = team_sum<L>(dp);
-        const bool uc = ss >= 1e-12f;
-        const float inv = fast_rsqrt(uc ? ss : 1e-12f);
+        const float dp = team_sum<L>(dot4(xp, S));
         const float al = uc ? inv * pr.unit * dp : 0.f;       // <nrm, G>,  G = unit S
         const float cg = inv * pr.unit, cx = -inv * inv * al;   // gxp = inv (G - al nrm) = cg S + cx xp
         const float4 gxp = make_float4(cg * S.x + cx * xp.x, cg * S.y + cx * xp.y, cg * S.z + cx * xp.z, cg * S.w + cx * xp.w);
@@ -831,11 +834,16 @@ bool pair_keys_sortable(int64_t ent_total, int64_t rel_total) {
     return rows > 0 && rows < (int64_t(1) << 31) - 1;
 }
 
-int pair_records_workspace(int64_t M, int rd, uint32_t *&rec, int32_t *&dst) {
+int pair_records_workspace(int64_t M, int rd, uint32_t *&rec, int32_t *&dst, float2 *&aux) {
     int rc = ensure_counts_work(M, (size_t)rd);
     if (rc) return rc;
+    if (M > g_c.pair_aux_cap) {
+        if ((rc = regrow(g_c.pair_aux, (size_t)M, "pair records aux"))) return rc;
+        g_c.pair_aux_cap = M;
+    }
     rec = g_c.rec;
     dst = g_c.dst;
+    aux = g_c.pair_aux;
     return KGE_OK;
 }
 
@@ -875,7 +883,7 @@ int pair_records_reduce(int model, int64_t M, int D, int rd, int64_t ent_total, 
     PairRed pr;
     pr.ent = tables[0]; pr.ctx = tables[2]; pr.auxe = tables[3];
     pr.g_ent = grads[0]; pr.g_auxe = grads[3];
-    pr.D = D; pr.R = (int)rel_total; pr.RD = rd; pr.unit = unit;
+    pr.D = D; pr.R = (int)rel_total; pr.RD = rd; pr.unit = unit; pr.aux = g_c.pair_aux;
     pr.magic = rel_total == 1 ? 0xFFFFFFFFu : (unsigned)(((uint64_t(1) << 32) + (uint64_t)rel_total - 1) / (uint64_t)rel_total);
     if (model == KGE_TRANSH) {   // normalised normal vectors, once per step
         static float *ctxn = nullptr;
