@@ -490,7 +490,11 @@ __global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // t
     const int row0 = a.tile_row0[tile];
     const int rows = min(RW2, a.bucket_start[r + 1] - row0);
     const int K = MODE == GEMM_PROJECT ? a.De : a.Dr;
-    const int ncols = MODE == GEMM_PROJECT ? a.Dr : a.De;     // <= LDBN, multiple of 4
+    // blockIdx.y: column block of NT*16 output columns (one block covers everything when NT*16 >= the output width; at small
+    // batches -- one 128-row tile per relation, fewer tiles than CUs -- the 7-tile instantiation is launched with two column
+    // blocks so that twice as many workgroups, each with half the matrix to stream, are in flight)
+    const int j0 = blockIdx.y * LDBN;
+    const int ncols = min(LDBN, (MODE == GEMM_PROJECT ? a.Dr : a.De) - j0);     // multiple of 4
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < RW2) {
@@ -528,8 +532,8 @@ __global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // t
             constexpr int u = decltype(uc)::value;                                                                           \
             const int idx = min(tid + 256 * u, BROWS * BQ - 1);                                                              \
             const int rr = idx / BQ, q = idx - rr * BQ;                                                                      \
-            const float *src = MODE == GEMM_PROJECT ? M + (long long)min((k0_) + rr, K - 1) * a.Dr + min(4 * q, ncols - 4)   \
-                                                    : M + (long long)min(rr, ncols - 1) * a.Dr + min((k0_) + 4 * q, K - 4);  \
+            const float *src = MODE == GEMM_PROJECT ? M + (long long)min((k0_) + rr, K - 1) * a.Dr + j0 + min(4 * q, ncols - 4) \
+                                                    : M + (long long)(j0 + min(rr, ncols - 1)) * a.Dr + min((k0_) + 4 * q, K - 4);  \
             rb[u] = *reinterpret_cast<const float4 *>(src);                                                                  \
         });                                                                                                                  \
     }
@@ -583,9 +587,9 @@ __global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // t
                 for (int v = 0; v < 4; v++) {
                     const int row = (4 * s2 + wave) * 16 + 4 * (lane >> 4) + v;
                     if (row < rows) {
-                        if (MODE == GEMM_PROJECT) a.P[(long long)s_slot[row] * a.Dr + j] = acc[s2][t][v];
+                        if (MODE == GEMM_PROJECT) a.P[(long long)s_slot[row] * a.Dr + j0 + j] = acc[s2][t][v];
                         else __builtin_amdgcn_global_atomic_fadd_f32(
-                                (__attribute__((address_space(1))) float *)(a.g_ent + (long long)s_ent[row] * a.De + j), acc[s2][t][v]);
+                                (__attribute__((address_space(1))) float *)(a.g_ent + (long long)s_ent[row] * a.De + j0 + j), acc[s2][t][v]);
                     }
                 }
             }
@@ -791,7 +795,11 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     ga.tile_rel = g_w.tile_rel; ga.tile_row0 = g_w.tile_row0; ga.n_tiles = g_w.n_tiles;
     ga.De = De; ga.Dr = Dr;
     const unsigned max_tiles = (unsigned)(slots / (v2 ? RW2 : 32) + R + 1);
+    // sparse buckets (config #4's auto batch: 46 rows per relation, ~one tile per relation, fewer tiles than CUs): two column
+    // blocks of 7 tiles per row tile instead of one of 13
+    const bool split_cols = v2 && slots < 256 * R && engine().transr_v1 == 0;
     if (v2 && Dr <= 112) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, 7>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
+    else if (v2 && split_cols) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, 7>), dim3(max_tiles, (Dr + 111) / 112), dim3(256), 0, stream, ga);
     else if (v2) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, 13>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
     else hipLaunchKernelGGL((rows_gemm_kernel<GEMM_PROJECT>), dim3(max_tiles, (Dr + TN - 1) / TN), dim3(256), 0, stream, ga);
     const bool lean = transr_lean_vector_stage(Dr);   // the lean vector stage writes every GP row that dgrad / wgrad read
@@ -801,6 +809,7 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     if (rc) return rc;
     if (v2) {
         if (De <= 112) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 7>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
+        else if (split_cols) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 7>), dim3(max_tiles, (De + 111) / 112), dim3(256), 0, stream, ga);
         else hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 13>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
         // the all-output-tiles wgrad (full 13 x 13 tile grid only) pays one 160 kB flush per relation change: only with
         // well-filled buckets (measured: 316 vs 400 us at 574 rows per relation, 131 vs 77 us at 46)
