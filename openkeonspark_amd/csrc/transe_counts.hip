@@ -376,16 +376,23 @@ __global__ __launch_bounds__(256) void bkt_scatter_kernel(const int32_t *__restr
         const int m = base + threadIdx.x + 256 * k;
         d[k] = m < M ? dst[m] : -2;
     }
-    for (int i = threadIdx.x; i < 1024; i += 256) scan[i] = i <= NB ? bucket_total[i] : 0;
     for (int i = threadIdx.x; i <= NB; i += 256) hist[i] = 0;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan, 4 elements per thread
-        int add[4];
+    {   // inclusive scan of the NB+1 totals (padded to 1024): 4 consecutive entries per thread, a shuffle scan per wave, the
+        // four wave totals through LDS -- two barriers (a Hillis-Steele scan over LDS took twenty)
+        __shared__ int wave_total[4];
+        int v[4], run = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const int i = threadIdx.x + 256 * k; add[k] = i >= off ? scan[i - off] : 0; }
+        for (int k = 0; k < 4; k++) { const int i = 4 * threadIdx.x + k; v[k] = i <= NB ? bucket_total[i] : 0; run += v[k]; v[k] = run; }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        int incl = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        if (lane == 63) wave_total[wave] = incl;
         __syncthreads();
+        int base = incl - run;
+        for (int w = 0; w < wave; w++) base += wave_total[w];
 #pragma unroll
-        for (int k = 0; k < 4; k++) scan[threadIdx.x + 256 * k] += add[k];
+        for (int k = 0; k < 4; k++) scan[4 * threadIdx.x + k] = base + v[k];
         __syncthreads();
     }
     // exclusive start of bucket i = scan[i - 1]
