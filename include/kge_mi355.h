@@ -120,7 +120,7 @@ const char *kge_version(void);
  *                        multiples of 4 up to 256, at most 63 negatives, ent_total*rel_total below 2^31) take the
  *                        pair-count path: int8 sign records keyed by (entity, relation), the backward applied once per pair
  *                        (csrc/pairs.hip); 0 = float records / atomics as for the other shapes
- *   "pair_counts_min_neg": fewest negatives per positive for that path (default 4)
+ *   "pair_counts_min_neg": fewest negatives per positive for that path; default 0 = the measured cross-over (TransH 5, TransD 3)
  *   "index_device_min":  training sets with at least this many lines are indexed on the device (rocPRIM sorts,
  *                        same arrays bit for bit); default 4194304, 0 = always, negative = never
  *   "hub_copies":        1 (default) = on the fp32-atomic TransH/TransD path, relation-side gradient rows that would

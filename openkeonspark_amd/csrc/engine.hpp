@@ -62,7 +62,7 @@ struct Engine {
     int64_t index_device_min = int64_t(1) << 22;  // training sets from this many lines on are indexed on the device (index_build.hip); < 0 = never
     int transr_lean = 1;        // TransR vector stage: the float4-per-lane kernel that also zero-fills GP (0 = generic fwdbwd_kernel + memset)
     int pair_counts = 1;        // TransH / TransD: int8 sign records keyed by (entity, relation) + per-pair backward (pairs.hip) instead of float records
-    int pair_counts_min_neg = 4;   // ... from this many negatives per positive (with one or two, the per-group work of the pair path outweighs it)
+    int pair_counts_min_neg = 0;   // ... from this many negatives per positive; 0 = the measured cross-over (TransH 5, TransD 3)
     int hub_copies = 1;         // atomic TransH/TransD path: spread the relation-side rows over copies when a row takes >= 128 adds per step
     int lp_v1 = 0;              // test hook: link prediction through the generic predict kernel on materialised candidate batches
     int transr_v1 = 0;          // test hook: 1 = the 32x32x2 / 32-row-tile TransR kernels even where the v2 tiles apply; 2 = v2 with its all-tiles wgrad forced

@@ -767,7 +767,10 @@ int pair_records_reduce(int model, int64_t M, int D, int rd, int64_t ent_total, 
 // does a step of this shape take the pair-count path?  (also behind kge_pair_path_active: Config places its sampler prefetch by it)
 bool pair_path_active(const kge_model_desc &m, int64_t n_pos, int64_t n_neg) {
     Engine &e = engine();
-    return e.pair_counts && m.ent_dim == m.rel_dim && n_neg >= e.pair_counts_min_neg && pair_counts_shape_ok(m.model, m.ent_dim, n_neg) &&
+    // measured cross-over (tools/pair_threshold_sweep.py, profiles/r02_h_pair_threshold_sweep.jsonl): the per-group work of the pair path
+    // is amortised from 5 negatives per positive on for TransH, from 3 for TransD (two rows per entity side on the float path)
+    const int64_t min_neg = e.pair_counts_min_neg > 0 ? e.pair_counts_min_neg : (m.model == KGE_TRANSD ? 3 : 5);
+    return e.pair_counts && m.ent_dim == m.rel_dim && n_neg >= min_neg && pair_counts_shape_ok(m.model, m.ent_dim, n_neg) &&
            pair_keys_sortable(m.ent_total, m.rel_total) && n_pos * (2 + n_neg) >= e.float_records_min &&
            n_pos * (2 + n_neg) < (int64_t(1) << 31);
 }

@@ -176,8 +176,8 @@ def test_config3_wn18rr_transh(wn_dir, nbatches, B, path):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# the projecting models with many negatives: the pair-count path (csrc/pairs.hip; chosen by the engine from 4 negatives and
-# 65 536 entity-side rows per step on)
+# the projecting models with many negatives: the pair-count path (csrc/pairs.hip; chosen by the engine from 5 (TransH) / 3 (TransD)
+# negatives and 65 536 entity-side rows per step on)
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("model,graph,nbatches,B", [("TransH", "wn", 8, 10854), ("TransD", "fb", 32, 8503)])
 def test_pair_count_path_many_negatives(wn_dir, fb_dir, model, graph, nbatches, B):

@@ -151,7 +151,7 @@ def grad_path(request):
     L.kge_set_option(b"float_records_min", 1 << 16)
     L.kge_set_option(b"counts_force_sort", 0)
     L.kge_set_option(b"pair_counts", 1)
-    L.kge_set_option(b"pair_counts_min_neg", 4)
+    L.kge_set_option(b"pair_counts_min_neg", 0)
 
 
 @pytest.mark.parametrize("model,E,R,D", CASES)
@@ -638,7 +638,7 @@ def test_sampled_entry_equals_general_entry(model, Dr):
             assert relerr(got[True][1][k], got[False][1][k]) < 1e-6, k
     finally:
         L.kge_set_option(b"float_records_min", 1 << 16)
-        L.kge_set_option(b"pair_counts_min_neg", 4)
+        L.kge_set_option(b"pair_counts_min_neg", 0)
 
 
 @pytest.mark.gpu
@@ -671,4 +671,4 @@ def test_pair_count_path_shapes(model, E, R, D, B, n):
             assert relerr(g_g[k], g_o[k]) < RTOL, (k, relerr(g_g[k], g_o[k]))
     finally:
         L.kge_set_option(b"float_records_min", 1 << 16)
-        L.kge_set_option(b"pair_counts_min_neg", 4)
+        L.kge_set_option(b"pair_counts_min_neg", 0)
