@@ -729,12 +729,16 @@ __global__ __launch_bounds__(256) void segsum_pairs_kernel(const uint32_t *__res
         Pair nxt;
         if (more) { int lo, hi; next_run(lo, hi); request(nxt, lo, hi); }
         // ---- integer sum of the run ----
-        int acc[4] = {0, 0, 0, 0};
+        int acc[4];
 #pragma unroll
-        for (int u = 0; u < W; u++) {
-            const uint32_t w = cur.lo + u < cur.hi ? cur.w[u] : 0u;
+        for (int j = 0; j < 4; j++) acc[j] = (int)(int8_t)(cur.w[0] >> (8 * j));
+        if (cur.hi - cur.lo > 1) {   // (most runs are one record long: the wave-uniform branch skips the other three unpack-and-adds)
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[j] += (int)(int8_t)(w >> (8 * j));
+            for (int u = 1; u < W; u++) {
+                const uint32_t w = cur.lo + u < cur.hi ? cur.w[u] : 0u;
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[j] += (int)(int8_t)(w >> (8 * j));
+            }
         }
         for (int i = cur.lo + W; i < cur.hi; i++) {   // long runs (hub pairs): the rest, one record at a time
             const long long id = __builtin_amdgcn_readlane(idl, i);
