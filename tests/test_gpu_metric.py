@@ -21,7 +21,7 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-def train_both(path, dim, nbatches, n, alpha, epochs, threads=8):
+def train_both(path, dim, nbatches, n, alpha, epochs, threads=8, model="TransE"):
     import openkeonspark_amd as pkg
     con = pkg.Config()
     con.prefetch_sampling = False
@@ -29,11 +29,11 @@ def train_both(path, dim, nbatches, n, alpha, epochs, threads=8):
     con.set_ent_neg_rate(n); con.set_alpha(alpha); con.set_margin(1.0); con.set_opt_method("SGD")
     con.set_test_link_prediction(True)
     con.init()
-    con.set_model_and_session(pkg.TransE)
+    con.set_model_and_session(getattr(pkg, model))
     init = con.get_parameters()
     kg = oracle.KG(path, work_threads=8, bern=0)
     kg.set_stream_states(con.get_stream_states())
-    orc = oracle.Model("transe", con.entTotal, con.relTotal, dim, dim, margin=1.0, params=init)
+    orc = oracle.Model(model.lower(), con.entTotal, con.relTotal, dim, dim, margin=1.0, params=init)
     B = con.batch_size
     _, untrained = con.link_prediction(test_head=True)
     steps = epochs * con.nbatches
@@ -101,4 +101,35 @@ def test_trained_model_reaches_the_oracle_trained_metrics(graph):
         assert abs(h10_g - h10_o) <= h10_tol, (side, h10_g, h10_o, h10_tol)
         assert mr_g < 0.75 * mr_0 and mr_o < 0.75 * mr_0, (side, mr_g, mr_o, mr_0)  # training helps: MR falls by > 25 %
         assert h10_g > h10_0 and h10_o > h10_0
+    assert abs(loss_g - loss_o) <= 0.15 * max(loss_o, 1e-3) + 0.01
+
+
+def test_transh_trained_through_the_pair_count_path_reaches_the_oracle_trained_metrics():
+    """The same comparison for TransH with 8 negatives per positive, every step through the pair-count path (csrc/pairs.hip:
+    int8 sign records keyed by (entity, relation), backward once per pair; forced here for this small graph): engine-trained
+    and oracle-trained tables ranked by the device ranker over the whole test set."""
+    from openkeonspark_amd import _lib
+    from openkeonspark_amd.synthetic import make_typed_dataset, SMALL_TYPED
+    path = make_typed_dataset("/tmp/okes_typed_small", SMALL_TYPED)
+    L = _lib.lib()
+    L.kge_set_option(b"float_records_min", 0)
+    try:
+        con, orc, untrained, (out_g, met_g, loss_g), (out_o, met_o, loss_o), steps = train_both(path, 32, 10, 8, 3.0, 30, model="TransH")
+        assert L.kge_pair_path_active(__import__("ctypes").byref(con._desc), con.batch_size, 8) == 1
+    finally:
+        L.kge_set_option(b"float_records_min", 1 << 16)
+    report = dict(graph="small_typed", model="TransH", negatives=8, steps=steps, final_loss_engine=loss_g, final_loss_oracle=loss_o)
+    for k in KEYS:
+        report[k] = dict(untrained=untrained[k], engine=met_g[k], oracle=met_o[k])
+    parity_report("metric_parity[transh-pair-count-path]", **report)
+    n_test = out_g.shape[0]
+    for side in ("r", "l"):
+        mr_g, mr_o, mr_0 = met_g[side + "_filter_rank"], met_o[side + "_filter_rank"], untrained[side + "_filter_rank"]
+        h10_g, h10_o = met_g[side + "_filter_tot"], met_o[side + "_filter_tot"]
+        ranks = 1.0 + out_g[:, 0 if side == "r" else 1, 1]
+        mr_tol = max(0.05 * mr_o, 2.5 * float(ranks.std()) / np.sqrt(len(ranks)))
+        assert abs(mr_g - mr_o) <= mr_tol, (side, mr_g, mr_o, mr_tol)
+        h10_tol = max(0.02, 2.5 * np.sqrt(max(h10_o * (1 - h10_o), 0.05) / n_test))
+        assert abs(h10_g - h10_o) <= h10_tol, (side, h10_g, h10_o, h10_tol)
+        assert mr_g < 0.9 * mr_0 and mr_o < 0.9 * mr_0, (side, mr_g, mr_o, mr_0)   # training helps
     assert abs(loss_g - loss_o) <= 0.15 * max(loss_o, 1e-3) + 0.01
