@@ -104,8 +104,9 @@ def test_trained_model_reaches_the_oracle_trained_metrics(graph):
     assert abs(loss_g - loss_o) <= 0.15 * max(loss_o, 1e-3) + 0.01
 
 
-def test_transh_trained_through_the_pair_count_path_reaches_the_oracle_trained_metrics():
-    """The same comparison for TransH with 8 negatives per positive, every step through the pair-count path (csrc/pairs.hip:
+@pytest.mark.parametrize("model", ["TransH", "TransD"])
+def test_trained_through_the_pair_count_path_reaches_the_oracle_trained_metrics(model):
+    """The same comparison for TransH / TransD with 8 negatives per positive, every step through the pair-count path (csrc/pairs.hip:
     int8 sign records keyed by (entity, relation), backward once per pair; forced here for this small graph): engine-trained
     and oracle-trained tables ranked by the device ranker over the whole test set."""
     from openkeonspark_amd import _lib
@@ -114,14 +115,14 @@ def test_transh_trained_through_the_pair_count_path_reaches_the_oracle_trained_m
     L = _lib.lib()
     L.kge_set_option(b"float_records_min", 0)
     try:
-        con, orc, untrained, (out_g, met_g, loss_g), (out_o, met_o, loss_o), steps = train_both(path, 32, 10, 8, 3.0, 30, model="TransH")
+        con, orc, untrained, (out_g, met_g, loss_g), (out_o, met_o, loss_o), steps = train_both(path, 32, 10, 8, 3.0, 30, model=model)
         assert L.kge_pair_path_active(__import__("ctypes").byref(con._desc), con.batch_size, 8) == 1
     finally:
         L.kge_set_option(b"float_records_min", 1 << 16)
-    report = dict(graph="small_typed", model="TransH", negatives=8, steps=steps, final_loss_engine=loss_g, final_loss_oracle=loss_o)
+    report = dict(graph="small_typed", model=model, negatives=8, steps=steps, final_loss_engine=loss_g, final_loss_oracle=loss_o)
     for k in KEYS:
         report[k] = dict(untrained=untrained[k], engine=met_g[k], oracle=met_o[k])
-    parity_report("metric_parity[transh-pair-count-path]", **report)
+    parity_report("metric_parity[%s-pair-count-path]" % model.lower(), **report)
     n_test = out_g.shape[0]
     for side in ("r", "l"):
         mr_g, mr_o, mr_0 = met_g[side + "_filter_rank"], met_o[side + "_filter_rank"], untrained[side + "_filter_rank"]
