@@ -23,6 +23,9 @@ def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=
     import openkeonspark_amd as pkg
     if sparse:   # the sharded step emits against a per-step row cache: norms from the gathered rows in both runs
         pkg._lib.lib().kge_set_option(b"inv_table_max_bytes", 0)
+    if os.environ.get("KGE_TEST_FORCE_PAIR_PATH") == "1":   # TransH / TransD: every step through the pair-count path
+        pkg._lib.lib().kge_set_option(b"float_records_min", 0)
+        pkg._lib.lib().kge_set_option(b"pair_counts_min_neg", 1)
     con = pkg.Config()
     con.set_in_path(os.path.join(GOLDEN, "kg_small"))
     con.set_work_threads(8); con.set_bern(1); con.set_dimension(48); con.set_nbatches(nbatches)  # B = 600 by default
@@ -73,6 +76,24 @@ def test_ranks_equal_single_process(tmp_path, model_name, opt, world):
         else:
             tol = 2e-5 if opt == "SGD" else 2e-4
             assert np.abs(res[world][0][k] - one[k]).max() <= tol * np.abs(one[k]).max(), k
+
+
+@pytest.mark.parametrize("model_name,opt", [("TransH", "SGD"), ("TransD", "Adam")])
+def test_ranks_equal_single_process_on_the_pair_count_path(tmp_path, model_name, opt, monkeypatch):
+    """The same equality with every rank's forward/backward going through the pair-count path (csrc/pairs.hip) on its slice of
+    the batch: the dense gradient image it fills is what the reduce-scatter exchanges."""
+    monkeypatch.setenv("KGE_TEST_FORCE_PAIR_PATH", "1")
+    res = _run_worlds(tmp_path, [1, 2], model_name, opt)
+    one = res[1][0]
+    for r in res[2]:
+        assert np.array_equal(r["states"], one["states"])
+        assert np.allclose(r["losses"], one["losses"], rtol=2e-5, atol=0)
+    for k in one.files:
+        if k in ("losses", "states"):
+            continue
+        assert np.array_equal(res[2][0][k], res[2][1][k]), k
+        tol = 2e-5 if opt == "SGD" else 2e-4
+        assert np.abs(res[2][0][k] - one[k]).max() <= tol * np.abs(one[k]).max(), k
 
 
 @pytest.mark.parametrize("world", [2, 4])
