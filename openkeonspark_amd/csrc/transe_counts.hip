@@ -700,6 +700,8 @@ __global__ __launch_bounds__(256) void segsum_pairs_kernel(const uint32_t *__res
     // one pair = one run of equal keys: [lo, hi) inside the chunk.  Its rows and first W records are REQUESTED one pair ahead
     // of the arithmetic (the dependent gathers, not the arithmetic, bounded the first version of this kernel).
     struct Pair { int lo, hi, row, rel; float4 x, cw, xa; float2 ai; uint32_t w[W]; };
+    int req_row = -1;                      // the entity row most recently fetched by request(), and its data
+    float4 req_x = make_float4(0.f, 0.f, 0.f, 0.f), req_xa = make_float4(0.f, 0.f, 0.f, 0.f);
     auto request = [&](Pair &q, int lo, int hi) {
         q.lo = lo; q.hi = hi;
         const unsigned key = (unsigned)__builtin_amdgcn_readlane(kl, lo);
@@ -707,9 +709,16 @@ __global__ __launch_bounds__(256) void segsum_pairs_kernel(const uint32_t *__res
         if (rel < 0) { row--; rel += R; }
         if (rel >= R) { row++; rel -= R; }
         q.row = row; q.rel = rel;
-        q.x = *reinterpret_cast<const float4 *>(pr.ent + (long long)row * D + lane4);
+        // the pairs of one entity are adjacent in key order (a dozen per entity at 25 negatives): its row(s) are fetched once, not
+        // once per pair -- the kernel is bound by the bytes it gathers (records + rows), and the rows were over half of them
+        if (row != req_row) {
+            req_x = *reinterpret_cast<const float4 *>(pr.ent + (long long)row * D + lane4);
+            if constexpr (MODEL == KGE_TRANSD) req_xa = *reinterpret_cast<const float4 *>(pr.auxe + (long long)row * D + lane4);
+            req_row = row;
+        }
+        q.x = req_x;
+        if constexpr (MODEL == KGE_TRANSD) q.xa = req_xa;
         q.cw = *reinterpret_cast<const float4 *>(pr.ctx + (long long)rel * D + lane4);
-        if constexpr (MODEL == KGE_TRANSD) q.xa = *reinterpret_cast<const float4 *>(pr.auxe + (long long)row * D + lane4);
 #pragma unroll
         for (int u = 0; u < W; u++) {
             const long long id = __builtin_amdgcn_readlane(idl, min(lo + u, hi - 1));
