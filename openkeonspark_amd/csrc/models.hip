@@ -761,7 +761,7 @@ long long pair_emit_blocks(int64_t n_pos);
 int pair_record_dwords(int D);
 void launch_pair_emit(int model, const FbArgs &a, hipStream_t stream);
 int pair_records_workspace(int64_t M, int rd, uint32_t *&rec, int32_t *&dst, float2 *&aux);
-int pair_records_reduce(int model, int64_t M, int D, int rd, int64_t ent_total, int64_t rel_total, const float *const tables[4],
+int pair_records_reduce(int model, int64_t M, int64_t n_int8, int D, int rd, int64_t ent_total, int64_t rel_total, const float *const tables[4],
                         float *const grads[4], float unit, hipStream_t stream);
 
 // does a step of this shape take the pair-count path?  (also behind kge_pair_path_active: Config places its sampler prefetch by it)
@@ -1063,7 +1063,7 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
             hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, a.loss_partials, (int)pair_emit_blocks(n_pos) + kDeferBlocks,
                                a.unit, d_loss);
         }
-        if ((rc = pair_records_reduce(m.model, M, a.D, rd, m.ent_total, m.rel_total, tables, grads, a.unit, stream))) return rc;
+        if ((rc = pair_records_reduce(m.model, M, 2 * n_pos, a.D, rd, m.ent_total, m.rel_total, tables, grads, a.unit, stream))) return rc;
         if (a.copies_rel) {
             const long long RD = (long long)m.rel_total * a.D;
             long long nb = (2 * RD + 255) / 256;

@@ -9,8 +9,8 @@
 // So the signs of all uses of (x, r) in a step can be summed as INTEGERS first and pushed through the
 // backward once per pair:
 //
-//   stage 1  pair_emit_kernel (this file): forward + hinge; per entity side one int8 sign record (D
-//            bytes, 4x smaller than a float row) keyed by x*R + r; the relation-side gradients (r^: an
+//   stage 1  pair_emit_kernel (this file): forward + hinge; per entity side one sign record keyed by
+//            x*R + r (a negative's: 2 bits per element, 64 bytes; the positive's two: int8 sums, D bytes); the relation-side gradients (r^: an
 //            integer sum; w^ / r_p: bilinear in (x, sign), accumulated in registers per group) are
 //            finished per GROUP and added to the hub copies of the relation tables.
 //   stage 2  pair_records_reduce (transe_counts.hip): the two-level counting sort by key, then
@@ -103,7 +103,9 @@ __device__ __forceinline__ void project(const float (&x)[E], const float (&xa)[E
 }  // namespace
 
 // One positive and its negatives per 16-lane team.  Records: slot 0 = h, slot 1 = t, slot 2+k = negative k
-// (record m = slot*n_pos + b, RD = 16*Q dwords each); a.dst[m] = x*R + r, or -1 for no record.
+// (record m = slot*n_pos + b); a.dst[m] = x*R + r, or -1 for no record.  The two records of the positive hold integer sums
+// (int8, RD = 16*Q dwords each, natural layout) at rec[m*RD]; the negatives' records hold signs only: 16 dwords each (lane l's
+// 4*Q elements as 2-bit fields of dword l, element 4q+j of the lane at bits 8q+2j) behind them, at rec[2*n_pos*RD + (m - 2*n_pos)*16].
 template <int MODEL, int Q>
 __global__ __launch_bounds__(256, 2) void pair_emit_kernel(FbArgs a) {
     constexpr int TEAMS = 256 / PT;
@@ -252,23 +254,24 @@ __global__ __launch_bounds__(256, 2) void pair_emit_kernel(FbArgs a) {
                 {
                     const s16x2 kh = pack16(code == 1 && act ? -1 : 0, code == 1 && act ? -1 : 0);   // kept h of a new-tail pair gets -s
                     const s16x2 kt = pack16(code == 0 && act ? 1 : 0, code == 0 && act ? 1 : 0);     // kept t of a new-head pair gets +s
-                    const s16x2 kxx = pack16(kx, kx);
-                    uint32_t rec[Q];
+                    // a negative's record holds signs only: 2 bits per element (00 / 01 / 11 = 0 / +1 / -1), the lane's 4*Q elements
+                    // in ONE dword -- a 64-byte record instead of 16*Q*4 bytes (the pair segsum is bound by the record bytes it gathers)
+                    uint32_t word = 0u;
 #pragma unroll
                     for (int q = 0; q < Q; q++) {
                         const int s0 = sign_of_bits(ev[4 * q]), s1 = sign_of_bits(ev[4 * q + 1]);
                         const int s2 = sign_of_bits(ev[4 * q + 2]), s3 = sign_of_bits(ev[4 * q + 3]);
                         gf[4 * q] = (float)s0; gf[4 * q + 1] = (float)s1; gf[4 * q + 2] = (float)s2; gf[4 * q + 3] = (float)s3;
                         const s16x2 s_lo = pack16(s0, s1), s_hi = pack16(s2, s3);
-                        rec[q] = bytes_of(s_lo * kxx, s_hi * kxx);
+                        word |= ((uint32_t)(s0 & 3) << (8 * q)) | ((uint32_t)(s1 & 3) << (8 * q + 2)) | ((uint32_t)(s2 & 3) << (8 * q + 4)) |
+                                ((uint32_t)(s3 & 3) << (8 * q + 6));
                         Ah_lo[q] += s_lo * kh; Ah_hi[q] += s_hi * kh;
                         At_lo[q] += s_lo * kt; At_hi[q] += s_hi * kt;
                     }
                     if (act) {
+                        if (kx < 0) word ^= (word & 0x55555555u) << 1;   // negate every 2-bit field: 01 <-> 11, 00 stays
                         const long long m = (long long)(2 + k0 + kk) * a.n_pos + b;
-                        uint32_t *pr = a.rec + m * (PT * Q);
-#pragma unroll
-                        for (int q = 0; q < Q; q++) pr[lane + PT * q] = rec[q];
+                        a.rec[2 * a.n_pos * (long long)(PT * Q) + ((long long)(k0 + kk) * a.n_pos + b) * PT + lane] = word;
                         if (lane == 0) a.pair_aux[m] = make_float2(aa, uc ? inv : -inv);
                     }
                 }

@@ -634,7 +634,8 @@ struct PairRed {
     const float *ent, *ctx, *auxe;    // ent_embeddings; per relation: TransH the NORMALISED normal vector (ctx_normalize_kernel), TransD rel_transfer; ent_transfer (TransD)
     float *g_ent, *g_auxe;
     const float2 *aux;                // per record: (a, +-1/|projected|) of its pair, from the emit kernel's forward
-    int D, R, RD;                     // embedding width, relations, dwords per record
+    int D, R, RD;                     // embedding width, relations, dwords per int8 record
+    long long n_int8;                 // records [0, n_int8) are int8 sums (RD dwords each); the rest are 2-bit sign records of 16 dwords
     unsigned magic;                   // ceil(2^32 / R): key / R by multiply-high (+ fix-up)
     float unit;
 };
@@ -699,7 +700,20 @@ __global__ __launch_bounds__(256) void segsum_pairs_kernel(const uint32_t *__res
     };
     // one pair = one run of equal keys: [lo, hi) inside the chunk.  Its rows and first W records are REQUESTED one pair ahead
     // of the arithmetic (the dependent gathers, not the arithmetic, bounded the first version of this kernel).
-    struct Pair { int lo, hi, row, rel; float4 x, cw, xa; float2 ai; uint32_t w[W]; };
+    struct Pair { int lo, hi, row, rel, signs; float4 x, cw, xa; float2 ai; uint32_t w[W]; };   // signs: bit u = record u is a 2-bit sign record
+    // record `id`: an int8 record gives this lane the dword of its four elements; a 2-bit sign record gives it the dword that
+    // holds them as the four fields of byte lane/16 (the emit kernel's 16-lane layout); which kind goes into bit u of `kinds`
+    const long long base2 = pr.n_int8 * pr.RD;
+    const int sh2 = 8 * (lane >> 4);
+    auto load_record = [&](long long id, int &kinds, int u) -> uint32_t {
+        if (id < pr.n_int8) return rec[id * pr.RD + (valid ? lane : 0)];
+        kinds |= 1 << u;
+        return rec[base2 + (id - pr.n_int8) * 16 + (lane & 15)];
+    };
+    // element j of this lane from a record dword of either kind
+    auto elem = [&](uint32_t w, bool sign2, int j) -> int {
+        return sign2 ? __builtin_amdgcn_sbfe((int)w, sh2 + 2 * j, 2) : (int)(int8_t)(w >> (8 * j));
+    };
     int req_row = -1;                      // the entity row most recently fetched by request(), and its data
     float4 req_x = make_float4(0.f, 0.f, 0.f, 0.f), req_xa = make_float4(0.f, 0.f, 0.f, 0.f);
     auto request = [&](Pair &q, int lo, int hi) {
@@ -719,10 +733,11 @@ __global__ __launch_bounds__(256) void segsum_pairs_kernel(const uint32_t *__res
         q.x = req_x;
         if constexpr (MODEL == KGE_TRANSD) q.xa = req_xa;
         q.cw = *reinterpret_cast<const float4 *>(pr.ctx + (long long)rel * D + lane4);
+        q.signs = 0;
 #pragma unroll
         for (int u = 0; u < W; u++) {
             const long long id = __builtin_amdgcn_readlane(idl, min(lo + u, hi - 1));
-            q.w[u] = rec[id * pr.RD + (valid ? lane : 0)];
+            q.w[u] = load_record(id, q.signs, u);
             if (u == 0) q.ai = pr.aux[id];   // every record of a pair carries the same two numbers
         }
     };
@@ -740,20 +755,22 @@ __global__ __launch_bounds__(256) void segsum_pairs_kernel(const uint32_t *__res
         // ---- integer sum of the run ----
         int acc[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[j] = (int)(int8_t)(cur.w[0] >> (8 * j));
+        for (int j = 0; j < 4; j++) acc[j] = elem(cur.w[0], cur.signs & 1, j);
         if (cur.hi - cur.lo > 1) {   // (most runs are one record long: the wave-uniform branch skips the other three unpack-and-adds)
 #pragma unroll
             for (int u = 1; u < W; u++) {
-                const uint32_t w = cur.lo + u < cur.hi ? cur.w[u] : 0u;
+                if (cur.lo + u < cur.hi) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[j] += (int)(int8_t)(w >> (8 * j));
+                    for (int j = 0; j < 4; j++) acc[j] += elem(cur.w[u], (cur.signs >> u) & 1, j);
+                }
             }
         }
         for (int i = cur.lo + W; i < cur.hi; i++) {   // long runs (hub pairs): the rest, one record at a time
             const long long id = __builtin_amdgcn_readlane(idl, i);
-            const uint32_t w = rec[id * pr.RD + (valid ? lane : 0)];
+            int kind = 0;
+            const uint32_t w = load_record(id, kind, 0);
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[j] += (int)(int8_t)(w >> (8 * j));
+            for (int j = 0; j < 4; j++) acc[j] += elem(w, kind & 1, j);
         }
         if (cur.row != cur_row) {
             if (cur_row >= 0) { flush_row(first_row); first_row = false; }
@@ -867,7 +884,7 @@ int pair_records_workspace(int64_t M, int rd, uint32_t *&rec, int32_t *&dst, flo
     return KGE_OK;
 }
 
-int pair_records_reduce(int model, int64_t M, int D, int rd, int64_t ent_total, int64_t rel_total, const float *const tables[4],
+int pair_records_reduce(int model, int64_t M, int64_t n_int8, int D, int rd, int64_t ent_total, int64_t rel_total, const float *const tables[4],
                         float *const grads[4], float unit, hipStream_t stream) {
     int rc;
     const int rows = (int)(ent_total * rel_total);
@@ -903,7 +920,7 @@ int pair_records_reduce(int model, int64_t M, int D, int rd, int64_t ent_total, 
     PairRed pr;
     pr.ent = tables[0]; pr.ctx = tables[2]; pr.auxe = tables[3];
     pr.g_ent = grads[0]; pr.g_auxe = grads[3];
-    pr.D = D; pr.R = (int)rel_total; pr.RD = rd; pr.unit = unit; pr.aux = g_c.pair_aux;
+    pr.D = D; pr.R = (int)rel_total; pr.RD = rd; pr.unit = unit; pr.aux = g_c.pair_aux; pr.n_int8 = n_int8;
     pr.magic = rel_total == 1 ? 0xFFFFFFFFu : (unsigned)(((uint64_t(1) << 32) + (uint64_t)rel_total - 1) / (uint64_t)rel_total);
     if (model == KGE_TRANSH) {   // normalised normal vectors, once per step
         static float *ctxn = nullptr;
