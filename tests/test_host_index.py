@@ -166,3 +166,31 @@ def test_model_batch_views_follow_the_reference_layout():
     ah, _, _ = m.get_all_instance(in_batch=True)
     assert ah.shape == (4, 4) and ah[1].tolist() == [10, 50, 90, 130]
     assert m.get_all_labels().shape == (16,) and m.get_all_instance()[2] is Cfg.batch_r
+
+
+def test_pair_count_path_selection_rule():
+    """kge_pair_path_active (include/kge_mi355.h): which TransH / TransD steps take the pair-count path -- host logic only, no
+    device needed: widths that are multiples of 4 up to 256, at most 63 negatives, from 5 (TransH) / 3 (TransD) negatives and
+    65 536 entity-side rows per step, ent_total*rel_total below 2^31."""
+    from openkeonspark_amd import _lib
+    L = _lib.lib()
+
+    def active(model, E, R, D, B, n):
+        d = _lib.ModelDesc(model, 0, E, R, D, D, 1.0, 0)
+        return L.kge_pair_path_active(ctypes.byref(d), B, n)
+
+    H, Dm, Em, Rm = _lib.TRANSH, _lib.TRANSD, _lib.TRANSE, _lib.TRANSR
+    assert active(H, 40943, 11, 200, 43417, 25) == 1 and active(Dm, 14541, 237, 200, 34014, 25) == 1
+    assert active(H, 40943, 11, 200, 43417, 4) == 0 and active(H, 40943, 11, 200, 43417, 5) == 1      # measured cross-over
+    assert active(Dm, 14541, 237, 200, 34014, 2) == 0 and active(Dm, 14541, 237, 200, 34014, 3) == 1
+    assert active(H, 40943, 11, 200, 2000, 25) == 0                                                    # 54 000 rows: a small step
+    assert active(H, 40943, 11, 202, 43417, 25) == 0 and active(H, 40943, 11, 260, 43417, 25) == 0     # width
+    assert active(H, 40943, 11, 200, 43417, 64) == 0                                                    # int8 range of the sums
+    assert active(Em, 14541, 237, 200, 34014, 25) == 0 and active(Rm, 14541, 237, 200, 34014, 25) == 0
+    assert active(H, 3_000_000, 1000, 200, 43417, 25) == 0                                             # keys must fit an int32
+    assert active(H, 14951, 1345, 200, 43417, 25) == 1                                                  # 20 M keys: radix-sort ordering
+    L.kge_set_option(b"pair_counts", 0)
+    try:
+        assert active(H, 40943, 11, 200, 43417, 25) == 0
+    finally:
+        L.kge_set_option(b"pair_counts", 1)
