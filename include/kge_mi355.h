@@ -91,6 +91,7 @@ INT *get_TPFP(INT r, REAL *score_pos, REAL *score_neg, REAL *threshold, REAL *un
  * ---------------------------------------------------------------------------------------- */
 enum {
     KGE_OK = 0,
+    KGE_NO_EVENT = 1,         /* kge_stream_wait_emit: no emit launch was recorded since the previous wait */
     KGE_ERR_NO_DEVICE = -1,   /* no usable gfx950 device / HIP runtime error */
     KGE_ERR_NO_DATASET = -2,  /* importTrainFiles / kge_import_train_arrays not done */
     KGE_ERR_BAD_ARG = -3,
@@ -215,7 +216,8 @@ int kge_forward_backward(const kge_model_desc *m, const float *const tables[KGE_
 /* Makes `stream` wait for the most recent launch of the TransE emit kernel (or of the pair-count path's emit kernel) (option "record_emit_event" = 1 records an event
  * behind every such launch).  Config.prefetch_sampling uses it to start the next batch's sampler on a side stream as soon as the
  * emit kernel -- the one bandwidth-bound kernel of the step -- has finished, so that it runs beside the small latency-bound
- * kernels that follow (bucketing, segmented sum, apply).  No emit kernel launched yet: returns at once. */
+ * kernels that follow (bucketing, segmented sum, apply).  Returns KGE_NO_EVENT (and makes `stream` wait for nothing) when no
+ * emit launch was recorded since the previous call: the caller then orders `stream` behind the step by an event of its own. */
 int kge_stream_wait_emit(void *stream);
 /* 1 when kge_forward_backward on a step of this shape takes the TransH / TransD pair-count path (whose emit kernel also records
  * the event above), else 0 */

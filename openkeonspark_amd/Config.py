@@ -499,8 +499,11 @@ class Config(object):
         self._slot ^= 1
         with torch.cuda.stream(self._side_stream):
             if behind_emit:
-                _lib.check(self.lib.kge_stream_wait_emit(ctypes.c_void_p(self._side_stream.cuda_stream)), self.lib)
-            else:
+                rc = _lib.check(self.lib.kge_stream_wait_emit(ctypes.c_void_p(self._side_stream.cuda_stream)), self.lib)
+                if rc == _lib.NO_EVENT:            # this step recorded no emit event: wait for everything enqueued so far
+                    done = torch.cuda.Event()
+                    done.record(main)
+            if done is not None:
                 self._side_stream.wait_event(done)  # slot reuse: its last reader is older than `done`
             dev, n_pos = self.sample_device(self._slot)
             ev = torch.cuda.Event()
@@ -662,10 +665,14 @@ class Config(object):
             raise KgeError("train_steps: a batch was sampled ahead by train_step(); use one or the other in a run")
         f = np.float32
         lr = np.empty(n_steps, np.float32)
+        powers = None
         if self._adam:
+            saved = (self._beta1_power, self._beta2_power)
             for i in range(n_steps):
                 lr[i] = self._adam_lr_t()
                 self._adam_advance()
+            powers = (self._beta1_power, self._beta2_power)
+            self._beta1_power, self._beta2_power = saved       # committed below, once the launch is known to have completed
         else:
             lr[:] = f(self.alpha)
         losses = torch.empty(n_steps, dtype=torch.float32, device=self.device)
@@ -680,6 +687,8 @@ class Config(object):
         if flag.value:
             raise KgeError("persistent training launch aborted: a grid barrier did not complete (is another process holding "
                            "compute units of this GPU?); the tables are in an intermediate state")
+        if powers is not None:
+            self._beta1_power, self._beta2_power = powers
         self.global_step += n_steps
         self._loss.copy_(losses[-1:])
         self.trainModel.loss = self._loss

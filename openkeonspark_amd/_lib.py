@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkge_mi355.so")
 
 TRANSE, TRANSH, TRANSR, TRANSD = 0, 1, 2, 3
+NO_EVENT = 1   # kge_stream_wait_emit: nothing was recorded since the previous wait (include/kge_mi355.h KGE_NO_EVENT)
 KGE_MAX_TABLES = 4
 
 

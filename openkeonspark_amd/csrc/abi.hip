@@ -306,6 +306,10 @@ int kge_get_stream_states(uint64_t *dst, INT n) {
 int kge_set_stream_states(const uint64_t *src, INT n) {
     Engine &e = engine();
     if (n != e.work_threads) return fail(KGE_ERR_BAD_ARG, "kge_set_stream_states: n must equal workThreads");
+    // a sampler launched on another (non-blocking) stream may still be writing the other half of the device state buffer, which
+    // the next upload reuses; nothing orders a blocking copy on the null stream behind it, so drain the device first (rare,
+    // control-path call: restore / tests)
+    if (e.dev.streams && device_ok()) (void)hipDeviceSynchronize();
     e.streams.assign(src, src + n);
     e.dev.streams_sync = 0;
     return KGE_OK;
@@ -362,7 +366,10 @@ int kge_pair_path_active(const kge_model_desc *m, INT n_pos, INT n_neg) { return
 
 int kge_stream_wait_emit(void *stream) {
     Engine &e = engine();
-    if (!e.emit_done) return KGE_OK;   // no emit kernel launched yet (or recording off): nothing to wait for
+    // nothing recorded since the last wait (recording off, or this step's path has no emit kernel): the caller must order the
+    // side stream some other way -- returning OK here would leave it with no dependency on the step at all
+    if (!e.emit_done || e.emit_seq == e.emit_waited) return KGE_NO_EVENT;
+    e.emit_waited = e.emit_seq;
     return hip_check(hipStreamWaitEvent((hipStream_t)stream, e.emit_done, 0), "wait for the emit kernel");
 }
 

@@ -51,6 +51,7 @@ struct Engine {
     int device_state = 0;  // 0 unknown, 1 ok, -1 none
     int record_emit_event = 0;  // 1: an event is recorded right behind every launch of the TransE emit kernel (kge_stream_wait_emit)
     hipEvent_t emit_done = nullptr;
+    unsigned long long emit_seq = 0, emit_waited = 0;   // events recorded / the last one a side stream was made to wait for
     int time_emit = 0;          // N > 0: record HIP events around every N-th launch of the TransE emit kernel (kge_last_kernel_ms / kge_kernel_ms_mean)
     static constexpr int kEmitRing = 512;   // event pairs: the timed launches of a bench run are read back AFTER the run, no sync inside it
     hipEvent_t ev_emit0[kEmitRing] = {}, ev_emit1[kEmitRing] = {};

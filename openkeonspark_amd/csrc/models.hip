@@ -494,6 +494,7 @@ static void record_emit_done(hipStream_t stream) {
     if (!eng.record_emit_event) return;
     if (!eng.emit_done) (void)hipEventCreateWithFlags(&eng.emit_done, hipEventDisableTiming);
     (void)hipEventRecord(eng.emit_done, stream);
+    eng.emit_seq++;
 }
 
 constexpr int kDeferBlocks = 128;
@@ -533,8 +534,10 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
         else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         if (timed) { (void)hipEventRecord(eng.ev_emit1[slot], stream); eng.emit_launches++; }
         record_emit_done(stream);
-    } else
+    } else {
         hipLaunchKernelGGL((transe_emit_kernel<L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        record_emit_done(stream);   // widths that are not multiples of 4 (dim 50): the prefetched sampler waits on this one too
+    }
     // groups with non sampler-shaped negatives: exact fp32 path into the residual accumulators
     // (no residual accumulators = record-only caller: the groups stay listed, kge_transe_deferred_groups reports them)
     if (!defer_pass) return;

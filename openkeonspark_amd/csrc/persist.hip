@@ -50,8 +50,16 @@ struct BarrierState {
 // thread 0 of every workgroup; returns false when the launch must bail out
 __device__ bool barrier_census(GridBarrier *gb, BarrierState &bs) {
     bs.xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;      // HW_REG_XCC_ID[3:0]
-    __hip_atomic_fetch_add(&gb->xcd_pop[bs.xcc * kLine], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(&gb->flat[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Two adds to different words from one thread are not ordered by themselves: a workgroup that sees flat == gridDim.x must also
+    // see every xcd_pop add, or it latches a population that is too small and its XCD releases early.  So the census add is a
+    // RETURNING atomic whose result is waited for (it has been performed once its value is back) before the flat add is issued.
+    const unsigned before = __hip_atomic_fetch_add(&gb->xcd_pop[bs.xcc * kLine], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (before >= gridDim.x) {    // (keeps the returned value live; cannot be true)
+        __hip_atomic_store(&gb->abort_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
+    __hip_atomic_fetch_add(&gb->flat[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spins = 0;
     while (ld_agent(&gb->flat[0]) < gridDim.x) {
         __builtin_amdgcn_s_sleep(2);
@@ -60,10 +68,16 @@ __device__ bool barrier_census(GridBarrier *gb, BarrierState &bs) {
             return false;
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // the populations are read only behind this
     bs.pop = ld_agent(&gb->xcd_pop[bs.xcc * kLine]);
     bs.n_xcd = 0;
-    for (int x = 0; x < 8; x++) bs.n_xcd += ld_agent(&gb->xcd_pop[x * kLine]) ? 1u : 0u;
+    unsigned total = 0;
+    for (int x = 0; x < 8; x++) { const unsigned c = ld_agent(&gb->xcd_pop[x * kLine]); bs.n_xcd += c ? 1u : 0u; total += c; }
     bs.gen = 0;
+    if (total != gridDim.x) {     // an incomplete census would let an XCD release early: drain instead
+        __hip_atomic_store(&gb->abort_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
     return true;
 }
 
@@ -430,10 +444,17 @@ extern "C" int kge_train_steps_persistent(const kge_model_desc *m, float *const 
     // 1024 threads: 16 waves per CU behind ONE barrier participant (<= 128 VGPRs); 512: half the waves, twice the registers
     const int D = a.D;
     const bool wide = e.persist_threads != 512;
+    // Cooperative launch: the runtime checks the grid against what can be co-resident and REFUSES one that cannot be
+    // (hipErrorCooperativeLaunchTooLarge) instead of leaving it to the bounded spins to find out half way through a step; its
+    // +15-19 us of host time is paid once per launch of n_steps steps.
+    void *kargs[] = {&pa};
+    hipError_t launch_err = hipSuccess;
 #define KGE_PERSIST(MODEL, LL, CC)                                                                                                 \
     {                                                                                                                              \
-        if (wide) hipLaunchKernelGGL((persistent_steps_kernel<MODEL, LL, CC, 1024>), dim3(blocks), dim3(1024), 0, stream, pa);     \
-        else hipLaunchKernelGGL((persistent_steps_kernel<MODEL, LL, CC, 512>), dim3(blocks), dim3(512), 0, stream, pa);            \
+        if (wide) launch_err = hipLaunchCooperativeKernel((const void *)persistent_steps_kernel<MODEL, LL, CC, 1024>, dim3(blocks), \
+                                                          dim3(1024), kargs, 0, stream);                                           \
+        else launch_err = hipLaunchCooperativeKernel((const void *)persistent_steps_kernel<MODEL, LL, CC, 512>, dim3(blocks),      \
+                                                     dim3(512), kargs, 0, stream);                                                 \
     }
 #define KGE_PERSIST_D(MODEL)                                                                   \
     if (D <= 16) KGE_PERSIST(MODEL, 16, 1) else if (D <= 32) KGE_PERSIST(MODEL, 16, 2)         \
@@ -446,6 +467,10 @@ extern "C" int kge_train_steps_persistent(const kge_model_desc *m, float *const 
     }
 #undef KGE_PERSIST_D
 #undef KGE_PERSIST
+    if (launch_err == hipErrorCooperativeLaunchTooLarge)
+        return fail(KGE_ERR_UNSUPPORTED, "kge_train_steps_persistent: one workgroup per compute unit cannot be co-resident on this device "
+                                         "(compute units masked or held by another process?)");
+    if ((rc = hip_check(launch_err, "persistent steps launch"))) return rc;
     if ((rc = hip_check(hipGetLastError(), "persistent steps launch"))) return rc;
     // every stream moves by n_steps batches (the launch sampled from the states it started with)
     hipLaunchKernelGGL(advance_streams_by_kernel, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, stream, e.dev.streams, (long long)W,

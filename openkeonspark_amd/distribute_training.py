@@ -152,7 +152,19 @@ def _step_of(path):
     return int(os.path.basename(path).split("model.ckpt-")[1].split(".")[0])
 
 
+def _atomic_savez(path, **arrays):
+    """np.savez under a temporary name, renamed into place: a reader (or a crash) never sees a half-written file."""
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as f:
+        np.savez(f, **arrays)
+    os.replace(tmp, path)
+
+
 def save_checkpoint(con, output_path, max_to_keep=10, write=True):
+    """COLLECTIVE in data-parallel runs.  Order of a SHARDED checkpoint (needs an `output_path` every rank can write and, on
+    restore, read -- a shared directory): every rank writes its shard file -> barrier -> rank 0 writes the main file and only
+    THEN the `checkpoint` pointer, then prunes.  The pointer therefore never names a step whose shard files are incomplete, and
+    older complete checkpoints are deleted only after the new one is whole."""
     arrays = checkpoint_arrays(con)
     step = con.global_step
     base = os.path.join(output_path, "model.ckpt-%d" % step)
@@ -160,14 +172,18 @@ def save_checkpoint(con, output_path, max_to_keep=10, write=True):
         os.makedirs(output_path, exist_ok=True)
         sh = con._shard
         rows = con.trainModel.parameter_lists["ent_embeddings"][:sh["hi"] - sh["lo"]].detach().cpu().numpy()
-        np.savez(base + ".shard%dof%d.npz" % (con.rank, con.world_size), rows=rows, lo=np.int64(sh["lo"]), hi=np.int64(sh["hi"]),
-                 ent_total=np.int64(con.entTotal))
+        _atomic_savez(base + ".shard%dof%d.npz" % (con.rank, con.world_size), rows=rows, lo=np.int64(sh["lo"]), hi=np.int64(sh["hi"]),
+                      ent_total=np.int64(con.entTotal))
+        import torch.distributed as dist
+        dist.barrier(group=getattr(con, "_pg", None))      # all shard files of this step exist before anything points at them
     if not write:
         return None
     os.makedirs(output_path, exist_ok=True)
-    np.savez(base + ".npz", **{k.replace("/", "__"): v for k, v in arrays.items()})
-    with open(os.path.join(output_path, "checkpoint"), "w") as f:
+    _atomic_savez(base + ".npz", **{k.replace("/", "__"): v for k, v in arrays.items()})
+    tmp = os.path.join(output_path, "checkpoint.tmp%d" % os.getpid())
+    with open(tmp, "w") as f:
         f.write('model_checkpoint_path: "%s"\n' % base)
+    os.replace(tmp, os.path.join(output_path, "checkpoint"))
     kept = sorted((p for p in glob.glob(os.path.join(output_path, "model.ckpt-*.npz")) if ".shard" not in p), key=_step_of)
     for old in kept[:-max_to_keep]:
         for part in glob.glob(old[:-4] + ".shard*of*.npz"):
@@ -211,7 +227,8 @@ def restore_checkpoint(con, path, allow_growth=True, arrays=None):
     """Load a checkpoint into an initialised Config (after set_model_and_session).  If the dataset
     gained entities since the checkpoint was written, entity tables are grown as the reference's
     `update_entities_and_model` does.  `arrays`: the checkpoint's contents when they were read elsewhere
-    (rank 0 reads the file and broadcasts it: the other ranks need not see the output directory)."""
+    (rank 0 reads the file and broadcasts it: for replicated tables the other ranks need not see the output directory; a
+    SHARDED entity table is read by every rank from the shard files, so that mode needs a shared `output_path`)."""
     import torch
     z = arrays if arrays is not None else {k.replace("__", "/"): v for k, v in np.load(path).items()}
     rng = np.random.default_rng(getattr(con, "seed", 0) + 1)
@@ -243,6 +260,8 @@ def restore_checkpoint(con, path, allow_growth=True, arrays=None):
     con.global_step = int(z.get("global_step", 0))
     if "rng_streams" in z and len(z["rng_streams"]) == con.workThreads:
         s = np.ascontiguousarray(z["rng_streams"], dtype=np.uint64)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()   # a sampler prefetched on the side stream may still be writing the other half of the state buffer
         con.lib.kge_set_stream_states(s.ctypes.data, con.workThreads)
         con._prefetched = None     # a batch drawn ahead belongs to the run that was interrupted
     return con.global_step

@@ -209,6 +209,129 @@ def test_config4_fb15k237_transr(fb_dir, nbatches, B):
     run_steps(con, kg, orc, B, n, alpha, steps=2, name="config4 FB15k-237 TransR 200x200 B=%d" % B, model="transr", dims=(200, 200))
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# configs[1]: the HEADLINE workload at its bench size, through the exact kernel chain bench.py times
+# ------------------------------------------------------------------------------------------------------------------
+def bench_engine(fb_dir):
+    """bench.py's engine, setting for setting (bench.py make_engine): FB15k-237-shaped graph, TransE dim 200, TF1 Adam 0.001,
+    25 negatives (bern), nbatches 8 -> B = 34 014, default counts_min_records, sampling prefetched behind the emit kernel."""
+    import openkeonspark_amd as pkg
+    con = pkg.Config()
+    con.set_in_path(fb_dir); con.set_work_threads(8); con.set_bern(1); con.set_dimension(200); con.set_nbatches(8)
+    con.set_ent_neg_rate(25); con.set_rel_neg_rate(0); con.set_alpha(0.001); con.set_margin(1.0); con.set_opt_method("Adam")
+    con.init()
+    con.set_model_and_session(pkg.TransE)
+    assert (con.entTotal, con.relTotal, con.batch_size) == (14541, 237, 34014)
+    assert con.use_counts and con.prefetch_sampling and not con.sparse_rows
+    assert con.batch_size * (3 + 25) >= con.counts_min_records        # the sign-count pipeline, not the fused atomic kernel
+    return con
+
+
+def test_config2_fb15k237_transe_adam_n25_bench_size(fb_dir):
+    """BASELINE configs[1] as bench.py runs it (B = 34 014 x 25 negatives, dim 200, TF1-semantics Adam, sampler prefetched on
+    the side stream): three `con.train_step()` calls -- row_inv_norm -> transe_emit_vec_kernel<64,1,4,1,true> -> bkt_hist /
+    scatter / sort -> segsum_kernel -> apply_counts_kernel(Adam) -- each against ONE oracle Adam step restarted from the
+    engine's own tables and Adam slots (TransE.py:26-51, distribute_training.py:95-101).  Checked per step: the batch the
+    engine trained on is the oracle sampler's batch bit for bit; loss to 1e-5; the gradient -- read back from Adam's first
+    moment, m1 = b1 m0 + (1 - b1) g -- to 1e-5 of its largest element on every row that is not a kink / tie row
+    (tests/parity_util.py, same accounting as run_steps); the second moment on those rows; and every element of the parameter
+    update must be one that a gradient within that 1e-5 can produce through Adam (parity_util.adam_update_explained)."""
+    import torch
+    from parity_util import kink_rows_chunked, adam_update_explained
+    con = bench_engine(fb_dir)
+    B, n, alpha, b1, b2, eps = 34014, 25, 0.001, 0.9, 0.999, 1e-8
+    names = con.trainModel.table_names
+    kg = oracle.KG(fb_dir, work_threads=8, bern=1)
+    kg.set_stream_states(con.get_stream_states())
+    orc = oracle.Model("transe", con.entTotal, con.relTotal, 200, 200, margin=1.0, params=con.get_parameters())
+    tot = dict(grad_rows=0, kink_elems=0, tie_groups=0, amplified=0, worst_steps=0.0, worst_gain=0.0, loss=0.0, grad=0.0, v=0.0)
+    for step in range(3):
+        p0 = con.get_parameters()
+        m0 = {k: con._adam_m[i].cpu().numpy() for i, k in enumerate(names)}
+        v0 = {k: con._adam_v[i].cpu().numpy() for i, k in enumerate(names)}
+        orc.params = {k: v.copy() for k, v in p0.items()}
+        orc.adam_m = {k: v.copy() for k, v in m0.items()}
+        orc.adam_v = {k: v.copy() for k, v in v0.items()}
+        orc.step = con.global_step
+        bh, bt, br, _ = kg.sampling(B, n, 0)
+        hm = orc.hinge_margins(bh, bt, br, B, n)
+        loss_o, g_o = orc.grad(bh, bt, br, B, n, nthreads=8)
+        lr_t = oracle.adam_lr_t(alpha, b1, b2, con.global_step + 1)
+        orc.apply_adam(g_o, alpha, b1, b2, eps)
+        loss_g = con.train_step()
+        used = con._dev_batch[con._slot ^ 1].cpu().numpy()       # (the other slot already holds the prefetched next batch)
+        assert np.array_equal(used[0], bh) and np.array_equal(used[1], bt) and np.array_equal(used[2], br), step
+        tot["loss"] = max(tot["loss"], abs(loss_g - loss_o) / abs(loss_o))
+        assert abs(loss_g - loss_o) <= RTOL * abs(loss_o), (step, loss_g, loss_o)
+        p1 = con.get_parameters()
+        kink = None
+        for i, k in enumerate(names):
+            m1 = con._adam_m[i].cpu().numpy().astype(np.float64)
+            v1 = con._adam_v[i].cpu().numpy().astype(np.float64)
+            scale = np.abs(g_o[k]).max()
+            g_eng = (m1 - b1 * m0[k].astype(np.float64)) / (1 - b1)
+            quantum = 4 * 2.0 ** -24 * np.abs(m1).max() / (1 - b1)                 # m1 is stored in fp32
+            diff = np.abs(g_eng - g_o[k])
+            bad = np.nonzero((diff > RTOL * scale + quantum).any(1))[0]
+            if len(bad) and kink is None:
+                kink, n_el = kink_rows_chunked(p0, bh, bt, br, B, n, KINK_TOL)
+                tied, n_tied = tie_group_rows(hm, p0, bh, bt, br, B, n)
+                tot["kink_elems"] += n_el; tot["tie_groups"] += n_tied
+                for kk in kink:
+                    kink[kk] |= tied[kk]
+            skip = kink[k] if kink is not None else set()
+            unexplained = set(bad.tolist()) - skip
+            assert not unexplained, (step, k, sorted(unexplained)[:10], "gradient rows outside 1e-5 with no |e| < KINK_TOL and no hinge within TIE_TOL")
+            tot["grad_rows"] += len(bad)
+            clean = np.ones(diff.shape[0], bool); clean[sorted(skip)] = False
+            tot["grad"] = max(tot["grad"], float(diff[clean].max() / scale))
+            # second moment on the clean rows: v1 = b2 v0 + (1 - b2) g^2, so a gradient within d moves it by (1 - b2)(2|g| d + d^2)
+            d = RTOL * scale
+            dv = np.abs(v1 - orc.adam_v[k])[clean]
+            allow = (1 - b2) * (2 * np.abs(g_o[k][clean]) * d + d * d) + 4 * 2.0 ** -24 * np.abs(v1).max()
+            assert (dv <= allow).all(), (step, k, float((dv - allow).max()))
+            tot["v"] = max(tot["v"], float(dv.max() / max(np.abs(v1).max(), 1e-30)))
+            rep = adam_update_explained(p0[k], m0[k], v0[k], g_o[k], p1[k].astype(np.float64) - p0[k], orc.params[k].astype(np.float64) - p0[k],
+                                        float(lr_t), b1, b2, eps, grad_rtol=RTOL, skip_rows=skip)
+            D = p0[k].shape[1]
+            assert rep["unexplained"].size == 0, (step, k, [(int(j // D), int(j % D)) for j in rep["unexplained"][:8]])
+            tot["amplified"] += rep["amplified"]
+            tot["worst_steps"] = max(tot["worst_steps"], rep["worst_steps"]); tot["worst_gain"] = max(tot["worst_gain"], rep["worst_gain"])
+    assert con.global_step == 3 and orc.step == 3
+    parity_report("config2 FB15k-237 TransE D=200 Adam n=25 B=34014 (bench chain, prefetch on)", steps=3, loss_relerr=tot["loss"],
+                  grad_relerr_clean_rows=tot["grad"], grad_rows_outside_1e5_all_kink_or_tie=tot["grad_rows"],
+                  elements_of_e_within_tol_of_zero=tot["kink_elems"], groups_with_hinge_within_tie_tol=tot["tie_groups"],
+                  adam_elements_beyond_1e3_of_a_step_all_explained=tot["amplified"], worst_in_steps=tot["worst_steps"],
+                  worst_adam_gain=tot["worst_gain"], v_relerr=tot["v"])
+    assert tot["grad"] <= RTOL and tot["grad_rows"] <= 64, tot
+
+
+def test_config2_loss_trajectory_20_steps(fb_dir):
+    """The same engine for 20 steps with no host synchronisation between them (the way bench.py drives it) against 20 oracle
+    Adam steps run INDEPENDENTLY from the same initial tables on the oracle sampler's batches: every step's loss within 2e-5
+    (a flipped kink element moves a parameter by a fraction of one 0.001 step; the loss is a mean over 850 350 hinges)."""
+    import torch
+    con = bench_engine(fb_dir)
+    B, n, alpha = 34014, 25, 0.001
+    kg = oracle.KG(fb_dir, work_threads=8, bern=1)
+    kg.set_stream_states(con.get_stream_states())
+    orc = oracle.Model("transe", con.entTotal, con.relTotal, 200, 200, margin=1.0, params=con.get_parameters())
+    dev_losses = [con.train_step(sync=False).clone() for _ in range(20)]
+    got = torch.stack([l.reshape(()) for l in dev_losses]).cpu().numpy().astype(np.float64)
+    want = np.zeros(20)
+    for step in range(20):
+        bh, bt, br, _ = kg.sampling(B, n, 0)
+        want[step] = orc.adam_step(bh, bt, br, B, n, alpha, nthreads=8)
+    rel = np.abs(got - want) / np.abs(want)
+    parity_report("config2 loss trajectory, 20 steps, engine vs independent oracle run", worst_relerr=float(rel.max()),
+                  first_loss=float(got[0]), last_loss=float(got[-1]))
+    assert (rel <= 2e-5).all(), rel.tolist()
+    assert got[-1] < got[0]          # it trains
+    # the rng streams: the engine has drawn one batch more than it trained on (the prefetched one)
+    kg.sampling(B, n, 0)
+    assert con.get_stream_states().tolist() == kg.stream_states().tolist()
+
+
 def test_config1_fb15k237_transe_auto_batch(fb_dir):
     """configs[0]: TransE dim 100, SGD, 1 negative, the reference's auto batch 2 721 (fused fp32-atomic kernel)."""
     n, alpha = 1, 0.01
