@@ -116,6 +116,12 @@ const char *kge_version(void);
  *   "float_records":     1 (default) = kge_forward_backward stores TransE/H/D gradient rows as records and sums
  *                        them by destination after a sort; 0 = fp32 atomic adds straight into the accumulators
  *   "float_records_min": smallest number of gradient rows per step that takes the record path (default 65536: measured cross-over, tools/sweep_paths.py)
+ *   "tables_changed": the caller has written device parameter tables itself (a copy into them, an all-gather, a restored
+ *                     checkpoint).  The TransE emit kernel keeps a table of 1/|row| that the full-table apply kernel
+ *                     (kge_transe_apply_counts_tables) refreshes row by row, so that no pre-pass over the tables is needed between
+ *                     steps; every kge_* entry point that writes tables marks it stale itself, this option is for writes the
+ *                     library cannot see.  Value ignored.
+ *   "inv_carry": 0 = recompute that table in front of every emit launch (test hook; default 1)
  *   "record_emit_event": 1 = record an event behind every TransE emit launch (kge_stream_wait_emit); default 0
  *   "pair_counts":       1 (default) = TransH / TransD steps of at least float_records_min entity-side rows (widths that are
  *                        multiples of 4 up to 256, at most 63 negatives, ent_total*rel_total below 2^31) take the

@@ -359,6 +359,7 @@ class Config(object):
                                                        self._shadow[0].data_ptr(), self._shadow[1].data_ptr(), self._stream()), self.lib)
 
     def _refresh_pointers(self):
+        self.lib.kge_set_option(b"tables_changed", 1)
         self._tab_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._tables])
         self._grad_ptrs = _lib.table_ptrs([g.data_ptr() for g in self._grads])
         self._numel = (ctypes.c_int64 * _lib.KGE_MAX_TABLES)(*[t.numel() for t in self._tables])
@@ -609,6 +610,7 @@ class Config(object):
                 self._counts.zero_()
                 self.apply_counts(denom, own=True)
                 all_gather_chunks(self._flat_p, self._flat_p[self._own[0]:self._own[1]], self._pg)
+                self.tables_changed()
                 self._refresh_shadow()
             else:
                 self.apply_counts(denom)
@@ -1102,6 +1104,12 @@ class Config(object):
         with open(path, "w") as f:
             f.write(json.dumps(self.get_parameters("list")))
 
+    def tables_changed(self):
+        """Tell the engine that device tables were written from outside its kernels (it keeps a per-row 1/|row| table for
+        the TransE emit kernel current across steps, include/kge_mi355.h "tables_changed").  Everything in this package that
+        writes tables calls it; call it yourself after writing `parameter_lists[...]` tensors directly."""
+        self.lib.kge_set_option(b"tables_changed", 1)
+
     def set_parameters_by_name(self, var_name, tensor):
         import torch
         if var_name in self.trainModel.parameter_lists:
@@ -1112,6 +1120,7 @@ class Config(object):
                 dst[:hi - lo].copy_(src.reshape(self.entTotal, -1)[lo:hi])
             else:
                 dst.copy_(src.reshape(dst.shape))
+            self.tables_changed()
             if getattr(self, "_shadow", None) is not None:
                 self._refresh_shadow()
 

@@ -220,6 +220,8 @@ int kge_set_option(const char *name, INT value) {
     std::string n = name ? name : "";
     if (n == "counts_force_sort") { engine().counts_force_sort = value != 0; return KGE_OK; }
     if (n == "inv_table_max_bytes") { engine().inv_table_max_bytes = value; return KGE_OK; }
+    if (n == "tables_changed") { tables_written(); return KGE_OK; }     // the caller wrote device tables itself (value ignored)
+    if (n == "inv_carry") { engine().inv_carry = value != 0; tables_written(); return KGE_OK; }
     if (n == "float_records") { engine().float_records = value != 0; return KGE_OK; }
     if (n == "float_records_min") { engine().float_records_min = value; return KGE_OK; }
     if (n == "index_device_min") { engine().index_device_min = value; return KGE_OK; }
@@ -381,22 +383,26 @@ int kge_forward_backward_sampled(const kge_model_desc *m, const float *const tab
 }
 
 int kge_sgd_update(float *d_p, float *d_g, int64_t n, float lr, void *stream) {
+    tables_written();
     return launch_sgd(d_p, d_g, n, lr, (hipStream_t)stream);
 }
 
 int kge_adam_update(float *d_p, float *d_m, float *d_v, float *d_g, int64_t n, float lr_t, float beta1, float beta2,
                     float eps, void *stream) {
+    tables_written();
     return launch_adam(d_p, d_m, d_v, d_g, n, lr_t, beta1, beta2, eps, (hipStream_t)stream);
 }
 
 int kge_sgd_update_tables(int32_t n_tables, float *const d_p[KGE_MAX_TABLES], float *const d_g[KGE_MAX_TABLES],
                           const INT numel[KGE_MAX_TABLES], float lr, void *stream) {
+    tables_written();
     return launch_sgd_tables(n_tables, d_p, d_g, (const int64_t *)numel, lr, (hipStream_t)stream);
 }
 
 int kge_adam_update_tables(int32_t n_tables, float *const d_p[KGE_MAX_TABLES], float *const d_m[KGE_MAX_TABLES],
                            float *const d_v[KGE_MAX_TABLES], float *const d_g[KGE_MAX_TABLES], const INT numel[KGE_MAX_TABLES],
                            float lr_t, float beta1, float beta2, float eps, void *stream) {
+    tables_written();
     return launch_adam_tables(n_tables, d_p, d_m, d_v, d_g, (const int64_t *)numel, lr_t, beta1, beta2, eps, (hipStream_t)stream);
 }
 

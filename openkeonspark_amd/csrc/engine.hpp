@@ -57,6 +57,15 @@ struct Engine {
     hipEvent_t ev_emit0[kEmitRing] = {}, ev_emit1[kEmitRing] = {};
     long long emit_launches = 0;   // timed launches since time_emit was switched on
     long long emit_seen = 0;       // all launches since then (time_emit = N times every N-th)
+    // per-row 1/|row| table of the vectorised TransE emit kernel.  inv_valid = 1: it holds the norms of the CURRENT contents of
+    // inv_for_ent / inv_for_rel (bf16 gather mode: of their shadows) -- set by the pre-pass, kept by the full-table apply kernel
+    // (which rewrites the entry of every row it changes), cleared by every other entry point that writes tables and by
+    // kge_set_option("tables_changed") for writes the library cannot see (Config.set_parameters, restore, all-gathers)
+    float *inv_norm = nullptr;
+    int64_t inv_cap = 0;
+    const float *inv_for_ent = nullptr, *inv_for_rel = nullptr;
+    int inv_valid = 0, inv_bf16 = 0;
+    int inv_carry = 1;          // 0 = always recompute the table in front of the emit kernel (test hook)
     int64_t inv_table_max_bytes = int64_t(256) << 20;  // TransE emit: per-row inverse-norm table only while the tables are this small
     int float_records = 1;              // TransH / TransD (and TransE without counts): record + segmented-sum path instead of fp32 atomics
     int64_t float_records_min = 1 << 16; // ... from this many gradient rows per step (below it the atomic kernel alone is quicker)
@@ -80,6 +89,8 @@ struct Engine {
 };
 
 Engine &engine();
+// some table was (or may have been) written by a path that does not refresh the emit kernel's 1/|row| table: it is stale from now on
+inline void tables_written() { engine().inv_valid = 0; }
 void set_error(const std::string &msg);
 int fail(int code, const std::string &msg);
 bool device_ok();

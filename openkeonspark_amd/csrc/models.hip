@@ -464,27 +464,25 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
 }
 
 // 1/max(|row|,1e-6): tf.nn.l2_normalize's rsqrt(max(sum x^2, 1e-12)) for every row of the two tables
-__global__ __launch_bounds__(256) void row_inv_norm_kernel(const float *__restrict__ ent, const float *__restrict__ rel,
-                                                           long long E, long long R, int D, float *__restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < E + R; row += (long long)gridDim.x * 4) {
-        const float *p = row < E ? ent + row * D : rel + (row - E) * D;
-        float s = 0.f;
-        for (int e = lane; e < D; e += 64) s += p[e] * p[e];
-        s = team_sum<64>(s);
-        if (lane == 0) out[row] = 1.0f / sqrtf(s >= 1e-12f ? s : 1e-12f);
-    }
-}
-
-__global__ __launch_bounds__(256) void row_inv_norm_bf16_kernel(const uint16_t *__restrict__ ent, const uint16_t *__restrict__ rel, long long E,
-                                                                long long R, int D, float *__restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < E + R; row += (long long)gridDim.x * 4) {
-        const uint16_t *p = row < E ? ent + row * D : rel + (row - E) * D;
-        float s = 0.f;
-        for (int e = lane; e < D; e += 64) { const float v = __uint_as_float((uint32_t)p[e] << 16); s += v * v; }
-        s = team_sum<64>(s);
-        if (lane == 0) out[row] = 1.0f / sqrtf(s >= 1e-12f ? s : 1e-12f);
+// The table's pre-pass, in the team shape of the apply kernel for this width (transe_team_shape) so that both produce the same bits
+template <int L, int C, bool BF16>
+__global__ __launch_bounds__(256) void row_inv_norm_kernel(const void *__restrict__ ent_, const void *__restrict__ rel_, long long E, long long R,
+                                                           int D, float *__restrict__ out) {
+    constexpr int TEAMS = 256 / L;
+    const int lane = threadIdx.x % L;
+    for (long long row = (long long)blockIdx.x * TEAMS + threadIdx.x / L; row < E + R; row += (long long)gridDim.x * TEAMS) {
+        float x[C];
+        if constexpr (BF16) {
+            const uint16_t *p = row < E ? (const uint16_t *)ent_ + row * D : (const uint16_t *)rel_ + (row - E) * D;
+#pragma unroll
+            for (int c = 0; c < C; c++) { const int e = lane + L * c; x[c] = e < D ? __uint_as_float((uint32_t)p[e] << 16) : 0.f; }
+        } else {
+            const float *p = row < E ? (const float *)ent_ + row * D : (const float *)rel_ + (row - E) * D;
+#pragma unroll
+            for (int c = 0; c < C; c++) { const int e = lane + L * c; x[c] = e < D ? p[e] : 0.f; }
+        }
+        const float inv = row_inv_norm<L, C>(x);
+        if (lane == 0) out[row] = inv;
     }
 }
 
@@ -514,13 +512,17 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
         // cache-sized (FB15k-237 x 200: 11.8 MB); beyond 256 MB the norms are computed from the gathered rows
         const bool inv_tab = a.inv_norm != nullptr;
         const bool bf16 = a.ent16 != nullptr;
-        if (inv_tab) {
-            long long nb = (a.ent_total + a.rel_total + 3) / 4;
+        Engine &eng0 = engine();
+        // the table is carried over from the previous step when the full-table apply kernel kept it current (transe_counts.hip)
+        const bool carried = eng0.inv_carry && eng0.inv_valid && eng0.inv_for_ent == a.ent && eng0.inv_for_rel == a.rel && eng0.inv_bf16 == (bf16 ? 1 : 0);
+        if (inv_tab && !carried) {
+            long long nb = (a.ent_total + a.rel_total + TEAMS - 1) / TEAMS;
             if (nb > 2048) nb = 2048;
-            if (bf16) hipLaunchKernelGGL(row_inv_norm_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.ent16, a.rel16,
+            if (bf16) hipLaunchKernelGGL((row_inv_norm_kernel<L, C, true>), dim3((unsigned)nb), dim3(256), 0, stream, (const void *)a.ent16, (const void *)a.rel16,
                                          (long long)a.ent_total, (long long)a.rel_total, a.D, const_cast<float *>(a.inv_norm));
-            else hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.ent, a.rel, (long long)a.ent_total,
-                                    (long long)a.rel_total, a.D, const_cast<float *>(a.inv_norm));
+            else hipLaunchKernelGGL((row_inv_norm_kernel<L, C, false>), dim3((unsigned)nb), dim3(256), 0, stream, (const void *)a.ent, (const void *)a.rel,
+                                    (long long)a.ent_total, (long long)a.rel_total, a.D, const_cast<float *>(a.inv_norm));
+            eng0.inv_for_ent = a.ent; eng0.inv_for_rel = a.rel; eng0.inv_bf16 = bf16 ? 1 : 0; eng0.inv_valid = 1;
         }
         Engine &eng = engine();
         const int slot = (int)(eng.emit_launches % Engine::kEmitRing);
@@ -611,18 +613,16 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
         int rc = hip_check(hipMemsetAsync(defer_count, 0, sizeof(int32_t), stream), "zero deferred count");
         if (rc) return rc;
     }
-    static float *inv_norm = nullptr;
-    static int64_t inv_cap = 0;
     const bool use_inv_table = (m.ent_total + m.rel_total) * (int64_t)m.ent_dim * 4 <= e.inv_table_max_bytes;
-    if (use_inv_table && m.ent_total + m.rel_total > inv_cap) {
-        if (inv_norm) (void)hipFree(inv_norm);
-        inv_norm = nullptr;
-        int rc = hip_check(hipMalloc(&inv_norm, sizeof(float) * (size_t)(m.ent_total + m.rel_total)), "alloc row inverse norms");
+    if (use_inv_table && m.ent_total + m.rel_total > e.inv_cap) {
+        if (e.inv_norm) (void)hipFree(e.inv_norm);
+        e.inv_norm = nullptr; e.inv_valid = 0;
+        int rc = hip_check(hipMalloc(&e.inv_norm, sizeof(float) * (size_t)(m.ent_total + m.rel_total)), "alloc row inverse norms");
         if (rc) return rc;
-        inv_cap = m.ent_total + m.rel_total;
+        e.inv_cap = m.ent_total + m.rel_total;
     }
     FbArgs a = {};
-    a.inv_norm = use_inv_table ? inv_norm : nullptr;
+    a.inv_norm = use_inv_table ? e.inv_norm : nullptr;
     if (e.shadow_ent && e.shadow_for_ent == ent && e.shadow_for_rel == rel && use_inv_table && m.ent_dim % 4 == 0 && !track_deferred) {
         a.ent16 = e.shadow_ent; a.rel16 = e.shadow_rel;     // bf16 gather mode: these tables have a registered, current shadow
     }

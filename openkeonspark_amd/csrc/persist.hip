@@ -330,6 +330,7 @@ extern "C" int kge_train_steps_persistent(const kge_model_desc *m, float *const 
                                           float beta2, float eps, float *d_losses, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     Engine &e = engine();
+    tables_written();
     if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_train_steps_persistent: no usable HIP device");
     if (!m || !tables || !grads || !h_lr || !d_losses || batchSize <= 0 || negRate < 0 || negRelRate < 0 || negRate + negRelRate < 1 || n_steps < 1)
         return fail(KGE_ERR_BAD_ARG, "kge_train_steps_persistent: bad arguments");

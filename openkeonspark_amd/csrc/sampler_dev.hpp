@@ -84,6 +84,33 @@ __device__ __forceinline__ int filtered_pick(const int32_t *__restrict__ vals, i
     return (int)(tmp + lo);
 }
 
+// The same pick with ONE memory round trip for groups of up to four known ids (most (h, r) / (t, r) groups of a sparse KG):
+// the four candidates are requested together (clamped, unconditional) and the monotone predicate is counted; longer lists
+// fall through to the binary search.
+__device__ __forceinline__ int filtered_pick_short(const int32_t *__restrict__ vals, int len, long long tmp) {
+    if (len > 4) return filtered_pick(vals, len, tmp);
+    if (len <= 0) return (int)tmp;
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = vals[j < len ? j : len - 1];
+    int lo = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) lo += (j < len && (long long)v[j] - j <= tmp) ? 1 : 0;
+    return (int)(tmp + lo);
+}
+
+// s advanced by n < 2^16 steps, n different in every lane: a masked multiply-add per bit with the first jump entries read
+// through compile-time offsets (scalar loads the compiler batches), as many rounds as the widest n of the wave needs
+__device__ __forceinline__ uint64_t lcg_skip_lanes(uint64_t s, unsigned n) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (!__any((n >> j) != 0u)) break;
+        const uint64_t t = c_jump.mulA[j] * s + c_jump.addC[j];
+        s = ((n >> j) & 1u) ? t : s;
+    }
+    return s;
+}
+
 // One scored triple of the batch: slot k of the positive at global batch position p (k = 0 the positive, 1..neg entity
 // negatives, then relation negatives), drawn exactly as virtual thread `id` of the reference draws it (Base.cpp:95-140).
 // `skip_batches` whole batches of this thread's slice are skipped first (a persistent launch samples step s from the

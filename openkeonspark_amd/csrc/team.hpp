@@ -45,6 +45,19 @@ __device__ __forceinline__ float fast_rsqrt(float x) {
     return y * (1.5f - 0.5f * x * y * y);
 }
 
+// 1/|row| as the TransE emit kernel's per-row table holds it (tf.nn.l2_normalize's rsqrt(max(sum x^2, 1e-12)), TransE.py:12-14),
+// from a row held in the team layout (lane l: elements l, l+L, ...; padding elements are 0).  ONE definition for the table's
+// pre-pass (row_inv_norm_kernel) and for the apply kernel that refreshes the entry of every row it rewrites: a step gets the
+// same bits whichever of the two produced its table (a resumed run recomputes it, an uninterrupted run carries it over).
+template <int L, int C>
+__device__ __forceinline__ float row_inv_norm(const float (&x)[C]) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; c++) s = __fmaf_rn(x[c], x[c], s);
+    s = team_sum<L>(s);
+    return 1.0f / sqrtf(s >= 1e-12f ? s : 1e-12f);
+}
+
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f ? 1.f : 0.f) - (x < 0.f ? 1.f : 0.f); }
 
 template <int L, int C>

@@ -991,6 +991,8 @@ struct ApplyArgs {
     long long E;
     uint16_t *sh, *sh2;   // bf16 shadows of p / p2 (gather mode "bf16"), kept equal to the rounded master copy; null otherwise
     long long row_lo;   // dense form on a row RANGE [row_lo, rows): S points at the image of row_lo (a rank's reduce-scattered chunk)
+    float *inv_out;     // dense full-table form: the emit kernel's 1/|row| table ([E + R], row-space index), refreshed for every row rewritten
+                        // here so that the next step needs no pre-pass; with bf16 shadows the norm is that of the ROUNDED row (what is gathered)
 };
 
 template <int L, int C, bool SPARSE>
@@ -1039,10 +1041,13 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
             for (int c = 0; c < C; c++) g[c] = 0.f;
         }
         float *pp = table + row * a.D;
+        float xnew[C];      // the row as it stands after this update (bf16 gather mode: as its shadow holds it)
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const int e = tm.lane + L * c;
+            xnew[c] = 0.f;
             if (e >= a.D) continue;
+            float pn = x[c];
             if (!SPARSE && a.adam) {
                 float *mp = mt + row * a.D + e, *vp = vt + row * a.D + e;
                 float mi = __fmul_rn(m_old[c], a.b1), vi = __fmul_rn(v_old[c], a.b2);
@@ -1051,15 +1056,22 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
                     vi = __fadd_rn(vi, __fmul_rn(__fmul_rn(g[c], g[c]), 1.0f - a.b2));
                 }
                 *mp = mi; *vp = vi;
-                const float pn = __fsub_rn(x[c], __fdiv_rn(__fmul_rn(a.lr, mi), __fadd_rn(__fsqrt_rn(vi), a.eps)));
+                pn = __fsub_rn(x[c], __fdiv_rn(__fmul_rn(a.lr, mi), __fadd_rn(__fsqrt_rn(vi), a.eps)));
                 pp[e] = pn;
                 if (sh) sh[row * a.D + e] = bf16_rne(pn);
             } else if (g[c] != 0.f) {
-                const float pn = __fsub_rn(x[c], __fmul_rn(a.lr, g[c]));
+                pn = __fsub_rn(x[c], __fmul_rn(a.lr, g[c]));
                 pp[e] = pn;
                 if (!SPARSE && sh) sh[row * a.D + e] = bf16_rne(pn);
             }
+            xnew[c] = (!SPARSE && sh) ? __uint_as_float((uint32_t)bf16_rne(pn) << 16) : pn;
             if (!SPARSE && touched != 0.f) { Sp[e] = 0; if (rs[c] != 0.f) rp[e] = 0.f; }
+        }
+        if constexpr (!SPARSE) {
+            if (a.inv_out) {       // (wave-uniform: a kernel argument)
+                const float inv_new = row_inv_norm<L, C>(xnew);
+                if (tm.lane == 0) a.inv_out[i] = inv_new;
+            }
         }
     }
 }
@@ -1276,6 +1288,7 @@ int kge_transe_reduce_apply_records_sgd(const kge_model_desc *m, const uint32_t 
                                         float *d_rel, int32_t *d_rows, int32_t *d_row_counts, int32_t *d_n_rows, INT denom, float lr,
                                         void *stream_) {
     if (!m || !d_ent || !d_rel || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_transe_reduce_apply_records_sgd: bad arguments");
+    tables_written();
     FuseArgs fz;
     fz.ent = d_ent; fz.rel = d_rel; fz.E = m->ent_total; fz.unit = 1.0f / (float)denom; fz.lr = lr;
     return reduce_records_impl(m, d_rec, d_dst, n_records, d_rows, d_row_counts, d_n_rows, &fz, (hipStream_t)stream_);
@@ -1286,6 +1299,7 @@ int kge_transe_apply_rows_sgd(const kge_model_desc *m, float *d_ent, float *d_re
     hipStream_t stream = (hipStream_t)stream_;
     if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_apply_rows_sgd: no usable HIP device");
     if (!m || !d_rows || !d_row_counts || !d_n_rows || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_rows_sgd: bad arguments");
+    tables_written();
     if (max_rows <= 0) return KGE_OK;
     const int D = m->ent_dim;
     if (D % 4 == 0) {   // the arithmetic of the fused kernel: a row gets the same bits whichever kernel handles it
@@ -1322,6 +1336,7 @@ int kge_transe_apply_counts(float *d_p, float *d_m, float *d_v, int32_t *d_count
     if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_apply_counts: no usable HIP device");
     if (rows <= 0) return KGE_OK;
     if (dim > 1024 || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_counts: bad sizes");
+    tables_written();
     ApplyArgs a = {};
     a.p = d_p; a.m = d_m; a.v = d_v; a.S = d_counts; a.resid = d_resid; a.rows = rows; a.D = dim; a.E = rows;
     a.unit = 1.0f / (float)denom; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.adam = adam;
@@ -1359,6 +1374,15 @@ int kge_transe_apply_counts_range(const kge_model_desc *m, float *const d_p[2], 
     }
     a.S = d_counts_chunk; a.rows = row_hi; a.row_lo = row_lo; a.E = m->ent_total; a.D = m->ent_dim;
     a.unit = 1.0f / (float)denom; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.adam = adam;
+    {
+        // the emit kernel's 1/|row| table stays current only when THIS launch rewrites its entries: the whole row space of exactly
+        // the tables it was computed for, in the same gather mode; any other update of those tables makes it stale
+        Engine &e = engine();
+        const bool keeps = e.inv_carry && e.inv_valid && e.inv_norm && row_lo == 0 && row_hi == all_rows && e.inv_for_ent == d_p[0] &&
+                           e.inv_for_rel == d_p[1] && e.inv_cap >= all_rows && e.inv_bf16 == (a.sh ? 1 : 0);
+        if (keeps) a.inv_out = e.inv_norm;
+        else tables_written();
+    }
     const int D = m->ent_dim;
 #define KGE_APPLY2(LL, CC)                                                                                  \
     {                                                                                                       \
@@ -1383,6 +1407,7 @@ int kge_transe_set_bf16_shadow(const kge_model_desc *m, const float *d_ent, cons
     Engine &e = engine();
     if (!d_ent16 || !d_rel16) {      // unregister: back to fp32 gathers
         e.shadow_ent = e.shadow_rel = nullptr; e.shadow_for_ent = e.shadow_for_rel = nullptr;
+        tables_written();
         return KGE_OK;
     }
     if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_set_bf16_shadow: no usable HIP device");
@@ -1392,6 +1417,7 @@ int kge_transe_set_bf16_shadow(const kge_model_desc *m, const float *d_ent, cons
     hipLaunchKernelGGL(to_bf16_kernel, dim3(2048), dim3(256), 0, stream, d_ent, d_ent16, ne);
     hipLaunchKernelGGL(to_bf16_kernel, dim3(256), dim3(256), 0, stream, d_rel, d_rel16, nr);
     e.shadow_ent = d_ent16; e.shadow_rel = d_rel16; e.shadow_for_ent = d_ent; e.shadow_for_rel = d_rel;
+    tables_written();
     return hip_check(hipGetLastError(), "bf16 shadow refresh launch");
 }
 

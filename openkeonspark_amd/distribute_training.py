@@ -242,6 +242,7 @@ def restore_checkpoint(con, path, allow_growth=True, arrays=None):
                 if sh["hi"] > sh["lo"]:
                     part = read_entity_rows(base, sh["lo"], sh["hi"], shapes[name][1])
                     con.trainModel.parameter_lists[name][:sh["hi"] - sh["lo"]].copy_(torch.from_numpy(part))
+                    con.tables_changed()
             else:
                 con.set_parameters_by_name(name, read_entity_rows(base, 0, rows, shapes[name][1]))
             continue

@@ -488,6 +488,45 @@ def test_prefetched_sampling_is_bit_identical(fb_dir, D):
         assert np.array_equal(runs[0][1][k], runs[1][1][k])
 
 
+@pytest.mark.parametrize("D,opt", [(200, "Adam"), (100, "SGD"), (64, "Adam"), (200, "SGD")])
+def test_inverse_norm_table_carried_across_steps_is_bit_identical(fb_dir, D, opt):
+    """The vectorised emit kernel reads 1/|row| from a per-row table.  The full-table apply kernel refreshes the entry of every
+    row it rewrites, so the pre-pass over the tables runs only when the table is stale (first step, after set_parameters).
+    Carrying the table (default) must give the same bits as recomputing it in front of every step (option inv_carry = 0),
+    including across a write of the tables from outside (set_parameters in mid-run rescales every entity row: a stale
+    table would normalise with the old norms) and for SGD, where untouched rows keep their old entry."""
+    from openkeonspark_amd.Config import Config
+    from openkeonspark_amd.TransE import TransE
+    from openkeonspark_amd import _lib
+    L = _lib.lib()
+    runs = []
+    try:
+        for carry in (0, 1):
+            L.kge_set_option(b"inv_carry", carry)
+            con = Config()
+            con.prefetch_sampling = False
+            con.counts_min_records = 0
+            con.set_in_path(fb_dir); con.set_work_threads(8); con.set_bern(1); con.set_dimension(D); con.set_nbatches(40)
+            con.set_ent_neg_rate(5); con.set_alpha(0.01); con.set_opt_method(opt)
+            con.init()
+            seeds = np.array(oracle.libc_rand_sequence(8), dtype=np.uint64)
+            con.lib.kge_set_stream_states(seeds.ctypes.data, 8)
+            con.set_model_and_session(TransE)
+            losses = []
+            for step in range(7):
+                losses.append(con.train_step())
+                if step == 2:
+                    p = con.get_parameters()
+                    p["ent_embeddings"] = (p["ent_embeddings"] * np.float32(1.5)).astype(np.float32)
+                    con.set_parameters(p)
+            runs.append((losses, con.get_parameters()))
+    finally:
+        L.kge_set_option(b"inv_carry", 1)
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for k in runs[0][1]:
+        assert np.array_equal(runs[0][1][k], runs[1][1][k]), k
+
+
 @pytest.mark.parametrize("model", ["transe", "transh", "transd", "transr"])
 def test_predict_matches_oracle(model):
     rng = np.random.default_rng(3)
