@@ -183,6 +183,18 @@ int kge_set_stream_states(const uint64_t *src, INT n);
  * *n_local receives the number of positives written (may be NULL). */
 int kge_sampling_device(int32_t *d_h, int32_t *d_t, int32_t *d_r, INT batchSize, INT negRate, INT negRelRate,
                         INT thread_lo, INT thread_hi, INT out_stride, INT *n_local, void *stream);
+
+/* The same batch, ARMED instead of launched: the sampler depends on the rng streams and the dataset only, never on the
+ * parameters, so the batch of step i+1 can be drawn while step i is being reduced.  The armed sampler rides in the launch of
+ * the next kernel of the sign-count / pair-count pipeline that leaves most wave slots idle -- the bucket scatter, one
+ * workgroup per CU -- as extra workgroups of that launch: no side stream, no events, no second queue for the command
+ * processor to arbitrate (the step is one in-order stream of launches).  kge_sampling_flush launches an armed sampler on its
+ * own when the step's path had no such kernel (and is a no-op otherwise); every other sampler entry point, the stream-state
+ * accessors and the persistent launch flush it first, so batches are always drawn in order.  The rng streams are accounted
+ * as advanced from the moment of the call (Base.cpp:149-172 semantics unchanged: same batches, same order, same bits). */
+int kge_sampling_attach(int32_t *d_h, int32_t *d_t, int32_t *d_r, INT batchSize, INT negRate, INT negRelRate,
+                        INT thread_lo, INT thread_hi, INT out_stride, INT *n_local, void *stream);
+int kge_sampling_flush(void *stream);
 /* number of batch positions owned by virtual threads [thread_lo, thread_hi) for this batchSize */
 INT kge_slice_positions(INT batchSize, INT thread_lo, INT thread_hi, INT *first_position);
 

@@ -483,8 +483,25 @@ class Config(object):
             dev, n_pos = self.sample_device(self._slot)
         else:
             dev, n_pos, ev = self._prefetched
-            main.wait_event(ev)
+            if ev is not None:            # (None: drawn on this stream by a sampler that rode in the scatter launch)
+                main.wait_event(ev)
         return dev, n_pos
+
+    def _attach_next_batch(self):
+        """Arm the sampler of the NEXT batch so that it rides in this step's bucket-scatter launch (kge_sampling_attach): the
+        sign-count path's way of drawing batch i+1 during step i -- one stream, no events.  Call _flush_next_batch() once the
+        step's forward launches are enqueued."""
+        stride = max(self._n_local, 1)
+        self._slot ^= 1
+        buf = self._ensure_dev_batch(stride)[self._slot]
+        nl = ctypes.c_int64(0)
+        _lib.check(self.lib.kge_sampling_attach(buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), self.batch_size,
+                                                self.negative_ent, self.negative_rel, self._thread_lo, self._thread_hi, stride,
+                                                ctypes.byref(nl), self._stream()), self.lib)
+        self._prefetched = (buf, nl.value, None)
+
+    def _flush_next_batch(self):
+        _lib.check(self.lib.kge_sampling_flush(self._stream()), self.lib)
 
     def _prefetch_next_batch(self, behind_emit=False):
         """behind_emit=True (the sign-count path): the side stream waits for THIS step's emit kernel only -- the one
@@ -599,9 +616,12 @@ class Config(object):
             if batch_h is None and self.prefetch_sampling:
                 self._prefetch_next_batch()
         elif self.use_counts and big:
+            ahead = batch_h is None and self.prefetch_sampling
+            if ahead:
+                self._attach_next_batch()              # rides in the scatter launch enqueued by forward_counts
             self.forward_counts(dev, n_pos, stride, denom, sampler_shaped=batch_h is None)
-            if batch_h is None and self.prefetch_sampling:
-                self._prefetch_next_batch(behind_emit=True)
+            if ahead:
+                self._flush_next_batch()               # (launched on its own if the step's path had no scatter kernel)
             if self.world_size > 1:
                 # int32 SUM is exact: rank g receives the summed counts of ITS rows, updates them, and the updated rows go round
                 from .parallel import reduce_scatter_sum, allreduce_sum, all_gather_chunks

@@ -66,6 +66,8 @@ def _declare(L):
     L.kge_get_stream_states.argtypes = [vp, i64]
     L.kge_set_stream_states.argtypes = [vp, i64]
     L.kge_sampling_device.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, ctypes.POINTER(i64), vp]
+    L.kge_sampling_attach.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, ctypes.POINTER(i64), vp]
+    L.kge_sampling_flush.argtypes = [vp]
     L.kge_slice_positions.restype = i64
     L.kge_slice_positions.argtypes = [i64, i64, i64, ctypes.POINTER(i64)]
     L.kge_table_shape.argtypes = [ctypes.POINTER(ModelDesc), ctypes.c_int, ctypes.POINTER(i64), ctypes.POINTER(i64)]

@@ -88,6 +88,7 @@ int ensure_device_index() {
 
 static int pull_streams() {
     Engine &e = engine();
+    { int rc = flush_attached_sampler(nullptr); if (rc) return rc; }   // an armed sampler has yet to write the states being read
     if (e.dev.streams_sync == 2) {
         int rc = hip_check(hipMemcpy(e.streams.data(), e.dev.streams, sizeof(uint64_t) * e.streams.size(),
                                      hipMemcpyDeviceToHost), "download streams");
@@ -311,7 +312,7 @@ int kge_set_stream_states(const uint64_t *src, INT n) {
     // a sampler launched on another (non-blocking) stream may still be writing the other half of the device state buffer, which
     // the next upload reuses; nothing orders a blocking copy on the null stream behind it, so drain the device first (rare,
     // control-path call: restore / tests)
-    if (e.dev.streams && device_ok()) (void)hipDeviceSynchronize();
+    if (e.dev.streams && device_ok()) { (void)flush_attached_sampler(nullptr); (void)hipDeviceSynchronize(); }
     e.streams.assign(src, src + n);
     e.dev.streams_sync = 0;
     return KGE_OK;
@@ -329,6 +330,16 @@ INT kge_slice_positions(INT batchSize, INT thread_lo, INT thread_hi, INT *first_
     if (first_position) *first_position = lo;
     return hi - lo;
 }
+
+int kge_sampling_attach(int32_t *d_h, int32_t *d_t, int32_t *d_r, INT batchSize, INT negRate, INT negRelRate,
+                        INT thread_lo, INT thread_hi, INT out_stride, INT *n_local, void *stream) {
+    int64_t nl = 0;
+    int rc = attach_sampler(d_h, d_t, d_r, batchSize, negRate, negRelRate, thread_lo, thread_hi, out_stride, &nl, (hipStream_t)stream);
+    if (n_local) *n_local = nl;
+    return rc;
+}
+
+int kge_sampling_flush(void *stream) { return flush_attached_sampler((hipStream_t)stream); }
 
 int kge_sampling_device(int32_t *d_h, int32_t *d_t, int32_t *d_r, INT batchSize, INT negRate, INT negRelRate,
                         INT thread_lo, INT thread_hi, INT out_stride, INT *n_local, void *stream) {

@@ -91,6 +91,12 @@ struct Engine {
 Engine &engine();
 // some table was (or may have been) written by a path that does not refresh the emit kernel's 1/|row| table: it is stale from now on
 inline void tables_written() { engine().inv_valid = 0; }
+// sampler.hip: the next batch's sampler riding in another kernel's launch (kge_sampling_attach)
+struct SamplerArgs;
+bool take_attached_sampler(SamplerArgs &a, unsigned &blocks);   // true: `a` / `blocks` describe it and it is no longer armed
+int flush_attached_sampler(hipStream_t stream);                 // launches an armed sampler on its own
+int attach_sampler(int32_t *d_h, int32_t *d_t, int32_t *d_r, int64_t B, int64_t neg, int64_t negrel, int64_t thread_lo,
+                   int64_t thread_hi, int64_t out_stride, int64_t *n_local_out, hipStream_t stream);
 void set_error(const std::string &msg);
 int fail(int code, const std::string &msg);
 bool device_ok();

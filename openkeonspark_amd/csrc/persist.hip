@@ -340,6 +340,7 @@ extern "C" int kge_train_steps_persistent(const kge_model_desc *m, float *const 
     if (adam && (!adam_m || !adam_v)) return fail(KGE_ERR_BAD_ARG, "kge_train_steps_persistent: Adam needs the moment tables");
     int rc = ensure_device_index();
     if (rc) return rc;
+    if ((rc = flush_attached_sampler(stream))) return rc;
     if (e.index.train_dup <= 0) return fail(KGE_ERR_NO_DATASET, "kge_train_steps_persistent: empty training set");
     if (m->ent_total != e.index.ent_total || m->rel_total != e.index.rel_total)
         return fail(KGE_ERR_BAD_ARG, "kge_train_steps_persistent: model and dataset sizes differ");

@@ -148,4 +148,108 @@ __device__ __forceinline__ void sample_slot(const SamplerArgs &a, long long p, l
     }
 }
 
+// every stream's state after this batch, into the OTHER half of the double buffer (the launch reads only the current half,
+// so no ordering between blocks is needed and no separate launch either); the host swaps the halves
+__device__ __forceinline__ void write_next_streams(const SamplerArgs &a, int kp, long long block, long long n_blocks) {
+    for (long long id = block * 256 + threadIdx.x; id < a.W; id += n_blocks * 256) {
+        long long lef = id * a.per_thread, rig = lef + a.per_thread;
+        if (rig > a.B) rig = a.B;
+        if (lef > a.B) lef = a.B;
+        a.streams_next[id] = lcg_skip(a.streams[id], (unsigned long long)(rig - lef) * (unsigned long long)(kp + a.neg));
+    }
+}
+
+// More than 64 slots per positive (over 63 negatives): one independent thread per slot, each with its own full jump.
+__device__ __forceinline__ void sample_block_wide(const SamplerArgs &a, long long block, long long n_blocks) {
+    const int kshift = a.kshift, kp = 1 + a.neg + a.negrel;
+    write_next_streams(a, kp, block, n_blocks);
+    for (long long g = block * 256 + threadIdx.x; (g >> kshift) < a.n_local; g += n_blocks * 256) {
+        const long long b = g >> kshift;
+        const long long k = g & ((1 << kshift) - 1);
+        if (k >= kp) continue;
+        int oh, ot, orr;
+        sample_slot(a, a.pos_lo + b, k, 0ull, oh, ot, orr);
+        const long long o = b + k * a.out_stride;
+        a.out_h[o] = oh; a.out_t[o] = ot; a.out_r[o] = orr;
+    }
+}
+
+constexpr int kBernLds = 2048;
+
+// Up to 64 slots per positive (the usual case).  The 1+neg+negrel draws of one positive sit in ADJACENT lanes (k = 0 the
+// positive, 1..neg entity negatives, then relation negatives; padded to a power of two <= 64): they read the same pos / grp
+// record and search the same groups, so those loads coalesce.  What the slots of a WAVE share is computed once:
+//   * the long jump (up to 64 table steps: slice offset x draws per positive) is done for the wave's FIRST positive only, on
+//     wave-uniform values (scalar unit); a lane then advances by the few draws between that state and its own slot -- at
+//     most 64 positives' worth, a masked multiply-add per bit (lcg_skip_lanes) -- instead of repeating the long jump;
+//   * the training-triple pick of a positive (one 64-bit modulo) is made by its k = 0 lane and handed to the others;
+//   * the Bernoulli table sits in LDS (one dependent global load less per negative).
+// Same draws in the same order as Base.cpp:95-140, so the batch is bit-identical to sample_slot's.
+// `block` of `n_blocks` 256-thread workgroups: the body of sample_kernel, also run by workgroups that ride along in another
+// kernel's launch (transe_counts.hip: the bucket scatter carries the NEXT batch's sampler, see kge_sampling_attach).
+__device__ __forceinline__ void sample_block(const SamplerArgs &a, long long block, long long n_blocks, float *bern_lds) {
+    const int kshift = a.kshift, kp = 1 + a.neg + a.negrel, kmask = (1 << kshift) - 1;
+    const unsigned long long draws = 1ull + 2ull * a.neg + a.negrel;
+    write_next_streams(a, kp, block, n_blocks);
+    const bool bern_in_lds = a.bern && a.rel_total <= kBernLds;
+    if (bern_in_lds) {
+        for (int i = threadIdx.x; i < a.rel_total; i += 256) bern_lds[i] = a.bern_prob[i];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const long long total = a.n_local << kshift;
+    const long long wave0 = block * 256 + (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63);
+    for (long long g0 = wave0; g0 < total; g0 += n_blocks * 256) {
+        // ---- wave-uniform: state in front of the first draw of the wave's first positive ----
+        const long long p0 = a.pos_lo + (g0 >> kshift);
+        const long long id0 = (long long)((unsigned)p0 / (unsigned)a.per_thread);   // owning virtual thread (Base.cpp:85-92); B < 2^31
+        const long long off0 = p0 - id0 * a.per_thread;
+        const uint64_t base0 = lcg_skip(a.streams[id0], (unsigned long long)off0 * draws);
+        // ---- per lane ----
+        const long long g = g0 + lane;
+        long long b = g >> kshift;
+        const int k = (int)(g & kmask);
+        const bool live = b < a.n_local && k < kp;
+        if (b >= a.n_local) b = a.n_local - 1;
+        const int kk = k < kp ? k : kp - 1;
+        const long long p = a.pos_lo + b;
+        const long long id = (long long)((unsigned)p / (unsigned)a.per_thread);
+        const long long off = p - id * a.per_thread;
+        const bool same = id == id0;                  // (a wave may cross into the next virtual thread's slice)
+        uint64_t s = same ? base0 : a.streams[id];
+        unsigned ahead = (unsigned)((same ? off - off0 : off) * (long long)draws);   // < 64 positives' draws
+        // draw 0 of a positive picks the training triple; entity negative k uses draws 1 + 2(k-1) (coin) and the next one
+        // (corruption); relation negative k uses draw 1 + 2 neg + (k - 1 - neg)   (Base.cpp:101-139)
+        if (kk >= 1) ahead += kk <= a.neg ? 1u + 2u * (unsigned)(kk - 1) : 1u + 2u * (unsigned)a.neg + (unsigned)(kk - 1 - a.neg);
+        s = lcg_skip_lanes(s, ahead);
+        s = lcg_step(s);                              // k = 0: the pick; entity negative: the coin; relation negative: its draw
+        const long long pick = (long long)mod_magic(s, a.pick_div, a.pick_magic) + (a.new_batch > 0 ? a.train_dup - a.new_batch : 0);
+        const long long i = __shfl((int)pick, lane & ~kmask);      // the positive's k = 0 lane holds the real one (train_dup < 2^31)
+        const int4 tr = a.pos[i];  // (h, t, r, -)
+        const int4 gq = a.grp[i];  // loaded together with it (not after the coin): one memory latency instead of two
+        int oh = tr.x, ot = tr.y, orr = tr.z;
+        if (kk >= 1 && kk <= a.neg) {
+            const float prob = a.bern ? (bern_in_lds ? bern_lds[orr] : a.bern_prob[orr]) : 500.0f;
+            const bool keep_head = (float)(s % 1000ull) < prob;      // Base.cpp:118: compared in float
+            s = lcg_step(s);                                           // Corrupt.h:25: the one draw of the corruption
+            if (keep_head) {  // corrupt_head(h, r): new TAIL outside tails(h,r)
+                const long long tmp = (long long)mod_u64_u32(s, (uint32_t)(a.ent_total - gq.y));
+                ot = min(filtered_pick_short(a.tails_hr + gq.x, gq.y, tmp), a.ent_total - 1);   // (clamp: only reachable in that degenerate case)
+            } else {          // corrupt_tail(t, r): new HEAD outside heads(t,r)
+                const long long tmp = (long long)mod_u64_u32(s, (uint32_t)(a.ent_total - gq.w));
+                oh = min(filtered_pick_short(a.heads_tr + gq.z, gq.w, tmp), a.ent_total - 1);
+            }
+        } else if (kk > a.neg) {  // Base.cpp:133-139: corrupt_rel(h, t)
+            const int2 gr = a.ht[i];
+            const long long tmp = (long long)mod_u64_u32(s, (uint32_t)(a.rel_total - gr.y));
+            orr = min(filtered_pick_short(a.rels_ht + gr.x, gr.y, tmp), a.rel_total - 1);
+        }
+        if (live) {
+            const long long o = b + (long long)k * a.out_stride;
+            a.out_h[o] = oh; a.out_t[o] = ot; a.out_r[o] = orr;
+        }
+    }
+}
+
+
 }  // namespace kge

@@ -24,6 +24,7 @@
 
 #include "engine.hpp"
 #include "team.hpp"
+#include "sampler_dev.hpp"
 
 namespace kge {
 
@@ -363,9 +364,17 @@ __global__ __launch_bounds__(256) void bkt_hist_kernel(const int32_t *__restrict
 // Every block first scans the NB+1 bucket totals itself (an exclusive scan of 513 ints in LDS is cheaper than the launch
 // of a scan kernel); block 0 publishes bucket_start[0..NB+1] for the kernels that follow.  Cursors count from 0 inside
 // each bucket; cursors and totals are re-zeroed by bkt_sort_kernel.
+// Workgroups beyond the scatter's own tiles (n_ride of them) run the NEXT batch's sampler (kge_sampling_attach): this launch
+// has one 256-thread workgroup per CU and waits on LDS / global atomics most of the time, the sampler is a latency-bound
+// pointer chase with no dependence on anything in the step -- together they take about as long as the longer of the two.
 __global__ __launch_bounds__(256) void bkt_scatter_kernel(const int32_t *__restrict__ dst, int M, int rpb, const int32_t *__restrict__ bucket_total,
                                                           int32_t *__restrict__ bucket_start, int32_t *__restrict__ cursor,
-                                                          int2 *__restrict__ pairs) {
+                                                          int2 *__restrict__ pairs, SamplerArgs ride, int n_tiles, int n_ride) {
+    if ((int)blockIdx.x >= n_tiles) {
+        __shared__ float bern_lds[kBernLds];
+        sample_block(ride, (long long)blockIdx.x - n_tiles, n_ride, bern_lds);
+        return;
+    }
     __shared__ int hist[NB + 1];
     __shared__ int base_of[NB + 1];
     __shared__ int scan[1024];
@@ -418,6 +427,16 @@ __global__ __launch_bounds__(256) void bkt_scatter_kernel(const int32_t *__restr
             pairs[pos] = make_int2(m, d[k]);
         }
     }
+}
+
+
+// the bucket scatter, with an armed sampler (if any) riding along
+static void launch_bkt_scatter(int n_tiles, int M, int rpb, int32_t *totals, int32_t *cursor, int2 *pairs, hipStream_t stream) {
+    SamplerArgs ride = {};
+    unsigned n_ride = 0;
+    if (take_attached_sampler(ride, n_ride) && upload_jump_table() != KGE_OK) n_ride = 0;   // (the upload cannot fail once the sampler's own has succeeded)
+    hipLaunchKernelGGL(bkt_scatter_kernel, dim3((unsigned)n_tiles + n_ride), dim3(256), 0, stream, g_c.dst, M, rpb, totals, g_c.bucket_start,
+                       cursor, pairs, ride, n_tiles, (int)n_ride);
 }
 
 // second level: counting sort of one bucket's pairs by destination row (rpb rows, LDS histogram), so
@@ -834,7 +853,7 @@ int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t 
         int32_t *totals = g_c.tile_hist, *cursor = g_c.tile_hist + (NB + 2);
         int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
         hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals);
-        hipLaunchKernelGGL(bkt_scatter_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals, g_c.bucket_start, cursor, pairs);
+        launch_bkt_scatter(n_tiles, (int)M, rpb, totals, cursor, pairs, stream);
         hipLaunchKernelGGL(bkt_sort_kernel, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
                            g_c.dst_sorted, g_c.ids_sorted, totals, cursor);
         n_valid_p = g_c.bucket_start + NB;
@@ -901,7 +920,7 @@ int pair_records_reduce(int model, int64_t M, int64_t n_int8, int D, int rd, int
         int32_t *totals = g_c.tile_hist, *cursor = g_c.tile_hist + (NB + 2);
         int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
         hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals);
-        hipLaunchKernelGGL(bkt_scatter_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals, g_c.bucket_start, cursor, pairs);
+        launch_bkt_scatter(n_tiles, (int)M, rpb, totals, cursor, pairs, stream);
         hipLaunchKernelGGL(bkt_sort_kernel, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
                            g_c.dst_sorted, g_c.ids_sorted, totals, cursor);
         n_valid_p = g_c.bucket_start + NB;   // start of the trash bucket == number of live records
@@ -1132,7 +1151,7 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
         int32_t *totals = g_c.tile_hist, *cursor = g_c.tile_hist + (NB + 2);
         int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
         hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals);
-        hipLaunchKernelGGL(bkt_scatter_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals, g_c.bucket_start, cursor, pairs);
+        launch_bkt_scatter(n_tiles, (int)M, rpb, totals, cursor, pairs, stream);
         hipLaunchKernelGGL(bkt_sort_kernel, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
                            g_c.dst_sorted, g_c.ids_sorted, totals, cursor);
         const int32_t *n_valid_p = g_c.bucket_start + NB;   // start of the trash bucket == number of live records

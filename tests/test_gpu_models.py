@@ -460,14 +460,19 @@ def test_sampled_training_matches_oracle_end_to_end(fb_dir):
     assert con.get_stream_states().tolist() == kg.stream_states().tolist()
 
 
-@pytest.mark.parametrize("D", [64, 50])
-def test_prefetched_sampling_is_bit_identical(fb_dir, D):
+@pytest.mark.parametrize("D,force_sort", [(64, 0), (50, 0), (64, 1)])
+def test_prefetched_sampling_is_bit_identical(fb_dir, D, force_sort):
     """Drawing batch i+1 on a side stream while step i finishes changes nothing: same losses, same
     parameters, bit for bit (the sampler never reads the parameters).  D = 50 takes the scalar emit kernel (widths that
     are not multiples of 4), whose launch must record the event the side stream waits for just as the vectorised one does:
-    with sync=False the host runs ahead, and an unordered sampler would overwrite batch slots that queued kernels still read."""
+    with sync=False the host runs ahead, and an unordered sampler would overwrite batch slots that queued kernels still read.
+    On the sign-count path the next batch's sampler is ARMED and rides in the step's bucket-scatter launch
+    (kge_sampling_attach); force_sort = 1 takes the reduction without a scatter kernel, where the armed sampler must be
+    launched on its own by kge_sampling_flush."""
     from openkeonspark_amd.Config import Config
     from openkeonspark_amd.TransE import TransE
+    from openkeonspark_amd import _lib
+    _lib.lib().kge_set_option(b"counts_force_sort", force_sort)
     runs = []
     for prefetch in (False, True):
         con = Config()
@@ -482,10 +487,12 @@ def test_prefetched_sampling_is_bit_identical(fb_dir, D):
         import torch
         dev_losses = [con.train_step(sync=False).clone() for _ in range(12)]   # no host sync between steps: the host runs ahead
         losses = [float(x) for x in torch.stack([l.reshape(()) for l in dev_losses]).cpu().numpy()]
-        runs.append((losses, con.get_parameters()))
+        runs.append((losses, con.get_parameters(), con.get_stream_states(before_prefetch=True)))
+    _lib.lib().kge_set_option(b"counts_force_sort", 0)
     assert runs[0][0] == runs[1][0]
     for k in runs[0][1]:
         assert np.array_equal(runs[0][1][k], runs[1][1][k])
+    assert runs[0][2].tolist() == runs[1][2].tolist()      # rewound by the one batch drawn ahead: the same rng states
 
 
 @pytest.mark.parametrize("D,opt", [(200, "Adam"), (100, "SGD"), (64, "Adam"), (200, "SGD")])
