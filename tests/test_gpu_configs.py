@@ -287,6 +287,19 @@ def test_config2_fb15k237_transe_adam_n25_bench_size(fb_dir):
                     kink[kk] |= tied[kk]
             skip = kink[k] if kink is not None else set()
             unexplained = set(bad.tolist()) - skip
+            if unexplained:      # what the closest switch points of those rows' groups look like (shown with the failure)
+                en = p0["ent_embeddings"].astype(np.float64); rn = p0["rel_embeddings"].astype(np.float64)
+                en /= np.sqrt(np.maximum((en * en).sum(-1, keepdims=True), 1e-12)); rn /= np.sqrt(np.maximum((rn * rn).sum(-1, keepdims=True), 1e-12))
+                hh, tt, rr = np.asarray(bh), np.asarray(bt), np.asarray(br)
+                for row in sorted(unexplained)[:4]:
+                    use = (rr == row) if k == "rel_embeddings" else ((hh == row) | (tt == row))
+                    gs = np.unique(np.nonzero(use)[0] % B)
+                    idx = (gs[:, None] + B * np.arange(n + 1)[None, :]).ravel()
+                    ee = np.abs(en[hh[idx]] + rn[rr[idx]] - en[tt[idx]])
+                    print("UNEXPLAINED", dict(step=step, table=k, row=int(row), groups=len(gs), smallest_abs_e=np.sort(ee.ravel())[:3].tolist(),
+                                              smallest_abs_hinge=np.sort(np.abs(hm[gs]).ravel())[:3].tolist(),
+                                              diff_over_scale=float(diff[row].max() / scale), elements_off=int((diff[row] > RTOL * scale + quantum).sum()),
+                                              row_norm_engine=float(np.linalg.norm(g_eng[row])), row_norm_oracle=float(np.linalg.norm(g_o[k][row]))))
             assert not unexplained, (step, k, sorted(unexplained)[:10], "gradient rows outside 1e-5 with no |e| < KINK_TOL and no hinge within TIE_TOL")
             tot["grad_rows"] += len(bad)
             clean = np.ones(diff.shape[0], bool); clean[sorted(skip)] = False
