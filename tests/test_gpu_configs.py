@@ -31,7 +31,12 @@ KINK_TOL = 1e-6
 KINK_TOL_TRANSR = 1e-6   # (there h^, t^ additionally come out of a 200-term projection summed in different orders: MFMA tiles vs a scalar loop)
 
 
-TIE_TOL = 1e-5   # |p - n + margin| below this: the two L1 scores (sums of D terms, added in different orders) may put the hinge on either side
+# |p - n + margin| below this: the two L1 scores may put the hinge on either side.  p and n are sums of D = 200 terms |e_i| of
+# normalised vectors, 10..20 in value, where one fp32 ulp is 1.9e-6; the engine adds them lane-strided + butterfly, the oracle
+# sequentially, and the normalised inputs already differ in the last bit: differences of several ulps of the partial sums occur
+# (observed on the bench batch: a flipped hinge 1.7e-5 from its switch point).  5e-5 covers it; of the 850 350 hinges of a bench
+# step about 20 lie inside the band.
+TIE_TOL = 5e-5
 
 
 def tie_group_rows(hm, params, bh, bt, br, B, N, tol=TIE_TOL):
