@@ -121,9 +121,6 @@ const char *kge_version(void);
  *                     (kge_transe_apply_counts_tables) refreshes row by row, so that no pre-pass over the tables is needed between
  *                     steps; every kge_* entry point that writes tables marks it stale itself, this option is for writes the
  *                     library cannot see.  Value ignored.
- *   "two_bit_records": dense TransE sign-count path, widths that are multiples of 4: the gradient records of the NEGATIVES hold
- *                     signs only, so they are written with 2 bits per element (a quarter of the int8 record's bytes);
- *                     1 = one byte store per lane, 2 = one dword store from every fourth lane (default), 0 = int8 records
  *   "inv_carry": 0 = recompute that table in front of every emit launch (test hook; default 1)
  *   "record_emit_event": 1 = record an event behind every TransE emit launch (kge_stream_wait_emit); default 0
  *   "pair_counts":       1 (default) = TransH / TransD steps of at least float_records_min entity-side rows (widths that are

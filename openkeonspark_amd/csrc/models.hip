@@ -244,11 +244,7 @@ __global__ __launch_bounds__(256) void transe_emit_kernel(FbArgs a) {
 //   * the integer gradient vectors are packed int16 pairs (v_pk_add_i16), bytes only when stored;
 //   * one global_load_dwordx4 per row chunk.  Record dword w = lane + L*q holds elements 4w..4w+3
 //     ("natural" layout, flagged to the reducers).
-// TWO: how the NEGATIVES' records are written -- 0: int8 like the positive's (one dword per lane into a.rec); 1 / 2: 2 bits per
-// element into a.rec2 (FbArgs::rec2), as one byte store per lane (1) or, packed across each quad of lanes with two DPP moves, as
-// one dword store from every fourth lane (2).  A template parameter, not a run-time branch: the kernel sits exactly on the
-// 128-VGPR step (four waves per SIMD) and a second live address computation costs it a wave.
-template <int L, int Q, int K, int WPE, bool INV_TAB, bool BF16 = false, int TWO = 0>
+template <int L, int Q, int K, int WPE, bool INV_TAB, bool BF16 = false>
 __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
     constexpr int TEAMS = 256 / L;
     __shared__ float red[TEAMS];
@@ -436,19 +432,12 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
                             At_lo[q] += s_lo * kt; At_hi[q] += s_hi * kt;
                             Ar_lo[q] += s_lo * kr; Ar_hi[q] += s_hi * kr;
                         }
-                        if constexpr (TWO != 0) {   // bytes 0x00 / 0x01 / 0xFF -> 2-bit two's complement, four elements per byte
+                        if (a.rec2) {      // (wave-uniform: a kernel argument)  bytes 0x00 / 0x01 / 0xFF -> 2-bit two's complement, 4 per byte
                             uint8_t *p2 = a.rec2 + (m - 3 * a.n_pos) * (long long)(L * Q);
 #pragma unroll
                             for (int q = 0; q < Q; q++) {
                                 const uint32_t x2 = rec[q] & 0x03030303u;
-                                const uint32_t byte = (x2 | (x2 >> 6) | (x2 >> 12) | (x2 >> 18)) & 0xFFu;
-                                if constexpr (TWO == 1) p2[lane + L * q] = (uint8_t)byte;
-                                else {
-                                    // lanes 4g .. 4g+3 -> one dword in lane 4g: pair up neighbours (quad_perm 1,0,3,2), then pairs (2,3,0,1)
-                                    const uint32_t pair = byte | ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xB1, 0xF, 0xF, false) << 8);
-                                    const uint32_t quad = pair | ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)pair, 0x4E, 0xF, 0xF, false) << 16);
-                                    if ((lane & 3) == 0) *reinterpret_cast<uint32_t *>(p2 + lane + L * q) = quad;
-                                }
+                                p2[lane + L * q] = (uint8_t)(x2 | (x2 >> 6) | (x2 >> 12) | (x2 >> 18));
                             }
                         } else
                             store_record<L, Q>(a, lane, m, rec);
@@ -550,18 +539,9 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
             if (!eng.ev_emit0[slot]) { (void)hipEventCreate(&eng.ev_emit0[slot]); (void)hipEventCreate(&eng.ev_emit1[slot]); }
             (void)hipEventRecord(eng.ev_emit0[slot], stream);
         }
-        const int two = a.rec2 ? eng.two_bit_records : 0;
-        if (bf16 && inv_tab) {
-            if (two) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true, true, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        } else if (inv_tab) {
-            if (two == 1) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true, false, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-            else if (two == 2) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true, false, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        } else {
-            if (two) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false, false, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        }
+        if (bf16 && inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        else if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         if (timed) { (void)hipEventRecord(eng.ev_emit1[slot], stream); eng.emit_launches++; }
         record_emit_done(stream);
     } else {
@@ -662,7 +642,7 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
     a.D = m.ent_dim; a.margin = m.margin; a.unit = 1.0f / (float)denom;
     a.loss_partials = e.dev.loss_partials;
     a.negative_rel = m.negative_rel;
-    a.rec = rec; a.rec2 = (m.ent_dim % 4 == 0 && e.two_bit_records) ? rec2 : nullptr; a.dst = dst; a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total; a.krel = krel;
+    a.rec = rec; a.rec2 = (m.ent_dim % 4 == 0) ? rec2 : nullptr; a.dst = dst; a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total; a.krel = krel;
     const int D = a.D;
     if (D % 4 == 0 && D <= 64) launch_emit<16, 4>(a, d_loss, stream);
     else if (D <= 16) launch_emit<16, 1>(a, d_loss, stream);

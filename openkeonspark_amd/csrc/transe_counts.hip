@@ -1170,8 +1170,7 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
     if (rc) return rc;
     const int D = m->ent_dim;
     const bool nat = D % 4 == 0;   // the vectorised emit kernel writes records in natural element order
-    // records from 3 n_pos on are 2-bit records when the emit kernel wrote them so (engine option two_bit_records, vectorised kernel only)
-    const int n_int8 = (nat && engine().two_bit_records) ? (int)(3 * n_pos) : (int)M;
+    const int n_int8 = (int)(3 * n_pos);
     const int rpb = (rows + NB - 1) / NB;
     if (rpb <= 8192 && !engine().counts_force_sort) {
         // ---- two-level counting sort (hand-written) + segmented sum: row spaces up to NB*8192 rows ----
