@@ -432,15 +432,7 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
                             At_lo[q] += s_lo * kt; At_hi[q] += s_hi * kt;
                             Ar_lo[q] += s_lo * kr; Ar_hi[q] += s_hi * kr;
                         }
-                        if (a.rec2) {      // (wave-uniform: a kernel argument)  bytes 0x00 / 0x01 / 0xFF -> 2-bit two's complement, 4 per byte
-                            uint8_t *p2 = a.rec2 + (m - 3 * a.n_pos) * (long long)(L * Q);
-#pragma unroll
-                            for (int q = 0; q < Q; q++) {
-                                const uint32_t x2 = rec[q] & 0x03030303u;
-                                p2[lane + L * q] = (uint8_t)(x2 | (x2 >> 6) | (x2 >> 12) | (x2 >> 18));
-                            }
-                        } else
-                            store_record<L, Q>(a, lane, m, rec);
+                        store_record<L, Q>(a, lane, m, rec);
                         if (lane == kk + u) my_dst = code[u] == 2 ? a.ent_total + row[u] : row[u];
                     }
                 }
@@ -602,8 +594,7 @@ int transe_deferred_groups(int32_t *out) {
 
 int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *rel, float *resid_ent, float *resid_rel,
                        const int32_t *d_h, const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
-                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream, bool track_deferred,
-                       uint8_t *rec2) {
+                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream, bool track_deferred) {
     // track_deferred = false: the caller guarantees sampler-shaped negatives (a device-sampled batch): no
     // deferral list, no counter reset, no fp32 pass
     Engine &e = engine();
@@ -642,7 +633,7 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
     a.D = m.ent_dim; a.margin = m.margin; a.unit = 1.0f / (float)denom;
     a.loss_partials = e.dev.loss_partials;
     a.negative_rel = m.negative_rel;
-    a.rec = rec; a.rec2 = (m.ent_dim % 4 == 0) ? rec2 : nullptr; a.dst = dst; a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total; a.krel = krel;
+    a.rec = rec; a.dst = dst; a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total; a.krel = krel;
     const int D = a.D;
     if (D % 4 == 0 && D <= 64) launch_emit<16, 4>(a, d_loss, stream);
     else if (D <= 16) launch_emit<16, 1>(a, d_loss, stream);

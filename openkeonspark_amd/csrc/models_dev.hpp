@@ -23,10 +23,6 @@ struct FbArgs {
     // TransE sign-count path (transe_counts.hip): int8 gradient records + destination rows
     uint32_t *rec;
     int32_t *dst;
-    // vectorised emit, engine-internal reduction only: the NEGATIVES' records (signs -1 / 0 / +1, slots 3..) go to this region
-    // with 2 bits per element -- byte (lane + L q) of record m - 3 n_pos holds lane's four elements of chunk q -- a quarter of
-    // the int8 form's bytes; the positive's h / t / r records (sums up to +-2N) stay int8 in `rec`.  null: all records int8
-    uint8_t *rec2;
     int ent_total, rel_total, krel;
     // indirection for the deferred groups of the sign-count path: when group_list != nullptr the
     // kernel walks group_list[0 .. *group_count) instead of 0 .. n_pos

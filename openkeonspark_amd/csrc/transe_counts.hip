@@ -31,8 +31,7 @@ namespace kge {
 void transe_team_shape(int D, int &L, int &C);
 int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *rel, float *resid_ent, float *resid_rel,
                        const int32_t *d_h, const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
-                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream, bool track_deferred,
-                       uint8_t *rec2 = nullptr);
+                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream, bool track_deferred);
 
 int transe_deferred_groups(int32_t *out);
 
@@ -42,8 +41,6 @@ int bits_for_rows(int64_t v) { int b = 1; while ((int64_t(1) << b) <= v) b++; re
 
 struct CtWork {
     uint32_t *rec = nullptr;
-    uint8_t *rec2 = nullptr;        // 2-bit records of the negatives (dense TransE path)
-    size_t rec2_bytes = 0;
     int32_t *dst = nullptr, *dst_sorted = nullptr, *ids = nullptr, *ids_sorted = nullptr;
     int32_t *n_valid = nullptr;
     int32_t *tile_hist = nullptr, *bucket_start = nullptr;   // LDS-bucket path: bucket totals + cursors, bucket starts
@@ -95,10 +92,6 @@ int ensure_counts_work(int64_t M, size_t rec_dwords) {
     if (rec_dwords > 0 && (size_t)M * rec_dwords > g_c.rec_elems) {
         if ((rc = regrow(g_c.rec, (size_t)M * rec_dwords, "counts records"))) return rc;
         g_c.rec_elems = (size_t)M * rec_dwords;
-    }
-    if (rec_dwords > 0 && (size_t)M * rec_dwords + 16 > g_c.rec2_bytes) {     // (one byte per int8 dword; + a dword of slack for the reads)
-        if ((rc = regrow(g_c.rec2, (size_t)M * rec_dwords + 16, "counts 2-bit records"))) return rc;
-        g_c.rec2_bytes = (size_t)M * rec_dwords + 16;
     }
     return KGE_OK;
 }
@@ -251,14 +244,10 @@ struct FuseArgs {
     float unit, lr;
 };
 
-// TWO: records with id >= n_int8 are 2-bit sign records in rec2 (FbArgs::rec2): byte (lane + L q) of record id - n_int8.  Both
-// forms are fetched by ONE dword load per (record, chunk) -- four lanes share a dword of a 2-bit record -- and decoded by the same
-// signed bit-field extracts with per-record offset / stride / width, so the loop has no branch around its loads.
-template <int L, int C, bool NAT, bool FUSE = false, bool TWO = false>
+template <int L, int C, bool NAT, bool FUSE = false>
 __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict__ rec, const int32_t *__restrict__ keys,
                                                      const int32_t *__restrict__ ids, const int32_t *__restrict__ n_valid_p,
-                                                     const int32_t *__restrict__ uidx, int32_t *__restrict__ S, int D, FuseArgs fz = FuseArgs(),
-                                                     const uint8_t *__restrict__ rec2 = nullptr, int n_int8 = 0) {
+                                                     const int32_t *__restrict__ uidx, int32_t *__restrict__ S, int D, FuseArgs fz = FuseArgs()) {
     // uidx == nullptr: S is the dense [rows, D] table and a run lands in row `key`;
     // uidx != nullptr: S is compact, a run lands in row uidx[position of the run] (unique-row index)
     constexpr int TEAMS = 256 / L;
@@ -304,16 +293,9 @@ __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict_
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            if constexpr (TWO) {
-                const bool two = id[u] >= n_int8;        // wave-uniform for full-wave teams (id comes from a lane broadcast)
-                const uint32_t *p = two ? reinterpret_cast<const uint32_t *>(rec2 + (long long)(id[u] - n_int8) * RD) : rec + (long long)id[u] * RD;
+            const uint32_t *p = rec + (long long)id[u] * RD;
 #pragma unroll
-                for (int q = 0; q < Q; q++) w[u][q] = p[two ? (lane + L * q) >> 2 : lane + L * q];
-            } else {
-                const uint32_t *p = rec + (long long)id[u] * RD;
-#pragma unroll
-                for (int q = 0; q < Q; q++) w[u][q] = p[lane + L * q];
-            }
+            for (int q = 0; q < Q; q++) w[u][q] = p[lane + L * q];
         }
 #pragma unroll
         for (int u = 0; u < U; u++) if (i0 + u >= n) k[u] = -1;
@@ -333,25 +315,13 @@ __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict_
                 cur_row = ur[u];
                 first_run = false;
             }
-            if constexpr (TWO) {
-                const bool two = id[u] >= n_int8;
-                const unsigned off0 = two ? 8u * (unsigned)(lane & 3) : 0u, step = two ? 2u : 8u;   // (L is a multiple of 4: (lane + L q) & 3 = lane & 3)
 #pragma unroll
-                for (int q = 0; q < Q; q++)
+            for (int q = 0; q < Q; q++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int c = 4 * q + j;
-                        if (c < C) acc[c] += __builtin_amdgcn_sbfe((int)w[u][q], off0 + step * j, step);
-                    }
-            } else {
-#pragma unroll
-                for (int q = 0; q < Q; q++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int c = 4 * q + j;
-                        if (c < C) acc[c] += (int)(int8_t)(w[u][q] >> (8 * j));
-                    }
-            }
+                for (int j = 0; j < 4; j++) {
+                    const int c = 4 * q + j;
+                    if (c < C) acc[c] += (int)(int8_t)(w[u][q] >> (8 * j));
+                }
         }
     }
     flush_run<L, C, NAT>(S, D, lane, cur_row, acc, true, stage);
@@ -1164,13 +1134,11 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
     if (rc) return rc;
     const int rows = (int)(m->ent_total + m->rel_total);
     // krel = 1: relation rows are ordinary rows E + r of the one row space (hub rows are split by the chunking)
-    // the vectorised emit kernel (widths that are multiples of 4) writes the negatives' records with 2 bits per element
     rc = launch_transe_emit(*m, d_ent, d_rel, d_resid_ent, d_resid_rel, d_h, d_t, d_r, n_pos, n_neg, stride, denom, g_c.rec, g_c.dst,
-                            1, d_loss, stream, d_resid_ent != nullptr && d_resid_rel != nullptr, g_c.rec2);
+                            1, d_loss, stream, d_resid_ent != nullptr && d_resid_rel != nullptr);
     if (rc) return rc;
     const int D = m->ent_dim;
     const bool nat = D % 4 == 0;   // the vectorised emit kernel writes records in natural element order
-    const int n_int8 = (int)(3 * n_pos);
     const int rpb = (rows + NB - 1) / NB;
     if (rpb <= 8192 && !engine().counts_force_sort) {
         // ---- two-level counting sort (hand-written) + segmented sum: row spaces up to NB*8192 rows ----
@@ -1191,8 +1159,8 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
     {                                                                                                                 \
         const long long chunks = (M + CHUNK - 1) / CHUNK;                                                             \
         const long long nb = (chunks + (256 / LL) - 1) / (256 / LL);                                                  \
-        if (nat) hipLaunchKernelGGL((segsum_kernel<LL, CC, true, false, true>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,  \
-                                    g_c.dst_sorted, g_c.ids_sorted, n_valid_p, nullptr, d_counts, D, FuseArgs(), g_c.rec2, n_int8); \
+        if (nat) hipLaunchKernelGGL((segsum_kernel<LL, CC, true>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,  \
+                                    g_c.dst_sorted, g_c.ids_sorted, n_valid_p, nullptr, d_counts, D);                 \
         else hipLaunchKernelGGL((segsum_kernel<LL, CC, false>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,     \
                                 g_c.dst_sorted, g_c.ids_sorted, n_valid_p, nullptr, d_counts, D);                     \
     }
@@ -1213,8 +1181,8 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
     {                                                                                                                 \
         const long long chunks = (M + CHUNK - 1) / CHUNK;                                                             \
         const long long nb = (chunks + (256 / LL) - 1) / (256 / LL);                                                  \
-        if (nat) hipLaunchKernelGGL((segsum_kernel<LL, CC, true, false, true>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,  \
-                                    g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, nullptr, d_counts, D, FuseArgs(), g_c.rec2, n_int8); \
+        if (nat) hipLaunchKernelGGL((segsum_kernel<LL, CC, true>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,  \
+                                    g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, nullptr, d_counts, D);               \
         else hipLaunchKernelGGL((segsum_kernel<LL, CC, false>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,     \
                                 g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, nullptr, d_counts, D);                   \
     }
