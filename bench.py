@@ -246,6 +246,9 @@ def main():
     devnull_fd = os.open(os.devnull, os.O_WRONLY)
     os.dup2(devnull_fd, 1)
     con = Config()
+    for key, val in os.environ.items():      # KGE_OPT_<engine option>=<int>: A/B runs of engine variants (include/kge_mi355.h kge_set_option)
+        if key.startswith("KGE_OPT_"):
+            con.lib.kge_set_option(key[8:].lower().encode(), int(val))
     con.device = "cuda:%d" % local_rank
     con.set_in_path(fb_dir)
     con.set_work_threads(WORK_THREADS)

@@ -13,6 +13,8 @@ con = pkg.Config()
 for key, val in os.environ.items():   # KGE_OPT_<engine option>=<int>
     if key.startswith("KGE_OPT_"):
         con.lib.kge_set_option(key[8:].lower().encode(), int(val))
+if os.environ.get("KGE_PREFETCH") is not None:    # 0: the sampler as its own kernel in front of every step (for profiling it)
+    con.prefetch_sampling = os.environ["KGE_PREFETCH"] != "0"
 con.set_in_path(make_dataset("/tmp/okes_%s" % spec["name"], spec)); con.set_work_threads(8); con.set_bern(1)
 con.set_dimension(dim); con.set_nbatches(nb); con.set_ent_neg_rate(neg); con.set_alpha(0.001); con.set_opt_method(opt)
 con.init()
