@@ -222,6 +222,7 @@ int kge_set_option(const char *name, INT value) {
     if (n == "counts_force_sort") { engine().counts_force_sort = value != 0; return KGE_OK; }
     if (n == "inv_table_max_bytes") { engine().inv_table_max_bytes = value; return KGE_OK; }
     if (n == "tables_changed") { tables_written(); return KGE_OK; }     // the caller wrote device tables itself (value ignored)
+    if (n == "counts_krel") { int k = 1; while (k * 2 <= value && k < 64) k *= 2; engine().counts_krel = k; return KGE_OK; }
     if (n == "inv_carry") { engine().inv_carry = value != 0; tables_written(); return KGE_OK; }
     if (n == "float_records") { engine().float_records = value != 0; return KGE_OK; }
     if (n == "float_records_min") { engine().float_records_min = value; return KGE_OK; }

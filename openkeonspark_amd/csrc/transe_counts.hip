@@ -242,6 +242,9 @@ struct FuseArgs {
     float *ent, *rel;
     long long E;
     float unit, lr;
+    // dense path with virtual relation-row copies (emit kernel's krel > 1): a key >= fold_E is copy (key - fold_E) / fold_R of
+    // relation (key - fold_E) % fold_R; its runs land in row fold_E + that relation, always with atomics (copies alias one row)
+    int fold_E, fold_R;
 };
 
 template <int L, int C, bool NAT, bool FUSE = false>
@@ -265,7 +268,9 @@ __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict_
 #pragma unroll
     for (int c = 0; c < C; c++) acc[c] = 0;
     int cur = keys[start];
-    int cur_row = uidx ? uidx[start] : cur;
+    const bool fold = !FUSE && fz.fold_R > 0;
+    auto row_of = [&](int key, int u) { return u >= 0 ? u : ((fold && key >= fz.fold_E) ? fz.fold_E + (key - fz.fold_E) % fz.fold_R : key); };
+    int cur_row = row_of(cur, uidx ? uidx[start] : -1);
     bool first_run = true;
     constexpr int U = 16;  // records in flight per team
     // the chunk's keys / record ids / unique-row indices: ONE coalesced load each (lane l holds entries l, l+L, ...),
@@ -307,12 +312,12 @@ __global__ __launch_bounds__(256) void segsum_kernel(const uint32_t *__restrict_
                     float *prow = cur < fz.E ? fz.ent + (long long)cur * D : fz.rel + ((long long)cur - fz.E) * D;
                     apply_row_nat<L, C>(acc, prow, D, lane, fz.unit, fz.lr);
                 } else {
-                    flush_run<L, C, NAT>(S, D, lane, cur_row, acc, first_run, stage);
+                    flush_run<L, C, NAT>(S, D, lane, cur_row, acc, first_run || (fold && cur >= fz.fold_E), stage);
                 }
 #pragma unroll
                 for (int c = 0; c < C; c++) acc[c] = 0;
                 cur = k[u];
-                cur_row = ur[u];
+                cur_row = row_of(k[u], uidx ? ur[u] : -1);
                 first_run = false;
             }
 #pragma unroll
@@ -1132,13 +1137,23 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
     if (M >= (int64_t(1) << 31)) return fail(KGE_ERR_UNSUPPORTED, "batch too large for the sign-count path");
     int rc = ensure_counts_work(M, rd);
     if (rc) return rc;
-    const int rows = (int)(m->ent_total + m->rel_total);
-    // krel = 1: relation rows are ordinary rows E + r of the one row space (hub rows are split by the chunking)
+    // Relation rows are hubs: every group sends one record to one of R rows (the Zipf head relation of the FB15k-237-shaped graph takes
+    // a sixth of them), and in the bucketing kernels all those records count on a handful of LDS bins -- same-address LDS atomics
+    // serialise, which set the tail of bkt_hist / bkt_scatter / bkt_sort (SQ_LDS_BANK_CONFLICT 64-92 % of their LDS cycles).  Group b
+    // therefore addresses copy b % krel of the relation rows (virtual rows E + c R + r); the segmented sum folds them back.
+    int krel = 1;
+    if (n_pos >= 4096 && m->rel_total > 0 && engine().counts_krel > 1) {
+        krel = engine().counts_krel;
+        while (krel > 1 && (int64_t)krel * m->rel_total > 2 * (m->ent_total + m->rel_total)) krel >>= 1;   // copies stay a minor part of the row space
+    }
+    const int rows = (int)(m->ent_total + (int64_t)krel * m->rel_total);
     rc = launch_transe_emit(*m, d_ent, d_rel, d_resid_ent, d_resid_rel, d_h, d_t, d_r, n_pos, n_neg, stride, denom, g_c.rec, g_c.dst,
-                            1, d_loss, stream, d_resid_ent != nullptr && d_resid_rel != nullptr);
+                            krel, d_loss, stream, d_resid_ent != nullptr && d_resid_rel != nullptr);
     if (rc) return rc;
     const int D = m->ent_dim;
     const bool nat = D % 4 == 0;   // the vectorised emit kernel writes records in natural element order
+    FuseArgs fold = FuseArgs();
+    if (krel > 1) { fold.fold_E = (int)m->ent_total; fold.fold_R = (int)m->rel_total; }
     const int rpb = (rows + NB - 1) / NB;
     if (rpb <= 8192 && !engine().counts_force_sort) {
         // ---- two-level counting sort (hand-written) + segmented sum: row spaces up to NB*8192 rows ----
@@ -1160,9 +1175,9 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
         const long long chunks = (M + CHUNK - 1) / CHUNK;                                                             \
         const long long nb = (chunks + (256 / LL) - 1) / (256 / LL);                                                  \
         if (nat) hipLaunchKernelGGL((segsum_kernel<LL, CC, true>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,  \
-                                    g_c.dst_sorted, g_c.ids_sorted, n_valid_p, nullptr, d_counts, D);                 \
+                                    g_c.dst_sorted, g_c.ids_sorted, n_valid_p, nullptr, d_counts, D, fold);           \
         else hipLaunchKernelGGL((segsum_kernel<LL, CC, false>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,     \
-                                g_c.dst_sorted, g_c.ids_sorted, n_valid_p, nullptr, d_counts, D);                     \
+                                g_c.dst_sorted, g_c.ids_sorted, n_valid_p, nullptr, d_counts, D, fold);               \
     }
         KGE_SHAPE_DISPATCH(D, KGE_SEG2)
 #undef KGE_SEG2
@@ -1182,9 +1197,9 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
         const long long chunks = (M + CHUNK - 1) / CHUNK;                                                             \
         const long long nb = (chunks + (256 / LL) - 1) / (256 / LL);                                                  \
         if (nat) hipLaunchKernelGGL((segsum_kernel<LL, CC, true>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,  \
-                                    g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, nullptr, d_counts, D);               \
+                                    g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, nullptr, d_counts, D, fold);         \
         else hipLaunchKernelGGL((segsum_kernel<LL, CC, false>), dim3((unsigned)nb), dim3(256), 0, stream, g_c.rec,     \
-                                g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, nullptr, d_counts, D);                   \
+                                g_c.dst_sorted, g_c.ids_sorted, g_c.n_valid, nullptr, d_counts, D, fold);             \
     }
     KGE_SHAPE_DISPATCH(D, KGE_SEG)
 #undef KGE_SEG
