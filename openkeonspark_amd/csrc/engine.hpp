@@ -65,7 +65,7 @@ struct Engine {
     int64_t inv_cap = 0;
     const float *inv_for_ent = nullptr, *inv_for_rel = nullptr;
     int inv_valid = 0, inv_bf16 = 0;
-    int counts_krel = 16;       // dense TransE path: virtual copies of the relation rows in the record sort (1 = none); a power of two
+    int counts_krel = 4;        // dense TransE path: virtual copies of the relation rows in the record sort (1 = none; measured 1/2/4/8/16/64: 4 best); a power of two
     int inv_carry = 1;          // 0 = always recompute the table in front of the emit kernel (test hook)
     int64_t inv_table_max_bytes = int64_t(256) << 20;  // TransE emit: per-row inverse-norm table only while the tables are this small
     int float_records = 1;              // TransH / TransD (and TransE without counts): record + segmented-sum path instead of fp32 atomics
