@@ -443,6 +443,11 @@ __device__ __forceinline__ void static_for(F &&f) {
         static_for<I + 1, N>(f);
     }
 }
+// keep-or-zero of a staged float4, component by component: `cond ? reg[u] : zero` on the whole vector becomes a select of two
+// ADDRESSES, which drags the register array it indexes into scratch memory (176 bytes per lane in the projection kernel:
+// every K chunk then went global -> scratch -> scratch load -> LDS)
+__device__ __forceinline__ float4 keep_if(bool c, const float4 &v) { return make_float4(c ? v.x : 0.f, c ? v.y : 0.f, c ? v.z : 0.f, c ? v.w : 0.f); }
+
 constexpr int RM2 = 64;          // rows per workgroup
 constexpr int KC2 = 40;          // K chunk: 10 MFMA k-steps
 constexpr int NT2 = 13;          // 16-column tiles per workgroup: 208 columns
@@ -460,22 +465,39 @@ constexpr int LDB2 = NT2 * 16;   // [k][j] layout, stride 208 = 16 mod 32: lanes
 constexpr int RT2 = 2;
 constexpr int RW2 = RM2 * RT2;   // rows per workgroup (128)
 
+// One K chunk (KC2 / 4 = 10 k-steps) of a wave's NS x NT accumulator tiles.  Software-pipelined by hand: the NS + NT operand reads
+// of k-step s+1 are issued BEFORE the NS*NT MFMAs of k-step s (two register sets used alternately), so an LDS round trip is
+// always covered by a full k-step of matrix work.  The compiler's own schedule for the plain loop was "one ds_read, s_waitcnt
+// lgkmcnt(0), its MFMAs" repeated -- the matrix pipe idle for an LDS latency per group of four MFMAs (MFMA busy 44 % / 30 % of the
+// project / dgrad kernels, rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES, profiles/r03_*).  NS + NT = 15 reads in flight is also what the
+// 4-bit lgkmcnt counter can express exactly.
 template <int MODE, int NT, int NS>
 __device__ __forceinline__ void gemm2_mfma_block(const float *__restrict__ As, const float *__restrict__ Bs, f32x4 (&acc)[RT2][NT], int wave, int lane) {
     constexpr int LDBN = NT * 16;
+    constexpr int STEPS = KC2 / 4;
+    const int kq = lane >> 4, j = lane & 15;
+    const float *a_base[NS];
 #pragma unroll
-    for (int ks = 0; ks < KC2; ks += 4) {
-        const int kk = ks + (lane >> 4);
-        float av[NS];
+    for (int s2 = 0; s2 < NS; s2++) a_base[s2] = As + ((4 * s2 + wave) * 16 + j) * LDA2 + kq;
+    const float *b_base = MODE == GEMM_PROJECT ? Bs + kq * LDBN + j : Bs + j * LDA2 + kq;
+    float av[2][NS], bv[2][NT];
+    auto fetch = [&](int buf, int st) {
 #pragma unroll
-        for (int s2 = 0; s2 < NS; s2++) av[s2] = As[((4 * s2 + wave) * 16 + (lane & 15)) * LDA2 + kk];
+        for (int s2 = 0; s2 < NS; s2++) av[buf][s2] = a_base[s2][4 * st];
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const float bv = MODE == GEMM_PROJECT ? Bs[kk * LDBN + t * 16 + (lane & 15)] : Bs[(t * 16 + (lane & 15)) * LDA2 + kk];
+        for (int t = 0; t < NT; t++) bv[buf][t] = MODE == GEMM_PROJECT ? b_base[4 * st * LDBN + t * 16] : b_base[t * 16 * LDA2 + 4 * st];
+    };
+    fetch(0, 0);
+    static_for<0, STEPS>([&](auto sc) {
+        constexpr int st = decltype(sc)::value;
+        constexpr int cur = st & 1;
+        if constexpr (st + 1 < STEPS) fetch(cur ^ 1, st + 1);
+        __builtin_amdgcn_sched_barrier(0);      // keep the next step's reads in front of this step's matrix work
 #pragma unroll
-            for (int s2 = 0; s2 < NS; s2++) acc[s2][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv, acc[s2][t], 0, 0, 0);
-        }
-    }
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int s2 = 0; s2 < NS; s2++) acc[s2][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][s2], bv[cur][t], acc[s2][t], 0, 0, 0);
+    });
 }
 
 template <int MODE, int NT>
@@ -541,13 +563,12 @@ __global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // t
     for (int k0 = 0; k0 < K; k0 += KC2) {
         if (k0 > 0) __syncthreads();          // the previous chunk's MFMA reads are done
         {
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             static_for<0, NA>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 const int idx = tid + 256 * u;
                 if (idx < RW2 * AQ) {
                     const int i = idx / AQ, q = idx - i * AQ;
-                    const float4 v = (i < rows && k0 + 4 * q < K) ? ra[u] : z;
+                    const float4 v = keep_if(i < rows && k0 + 4 * q < K, ra[u]);
                     float2 *dst = reinterpret_cast<float2 *>(&As[i * LDA2 + 4 * q]);   // stride 42 floats: 8-byte aligned
                     dst[0] = make_float2(v.x, v.y);
                     dst[1] = make_float2(v.z, v.w);
@@ -559,9 +580,9 @@ __global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // t
                 if (idx < BROWS * BQ) {
                     const int rr = idx / BQ, q = idx - rr * BQ;
                     if (MODE == GEMM_PROJECT) {
-                        *reinterpret_cast<float4 *>(&Bs[rr * LDBN + 4 * q]) = (k0 + rr < K && 4 * q < ncols) ? rb[u] : z;
+                        *reinterpret_cast<float4 *>(&Bs[rr * LDBN + 4 * q]) = keep_if(k0 + rr < K && 4 * q < ncols, rb[u]);
                     } else {
-                        const float4 v = (rr < ncols && k0 + 4 * q < K) ? rb[u] : z;
+                        const float4 v = keep_if(rr < ncols && k0 + 4 * q < K, rb[u]);
                         float2 *dst = reinterpret_cast<float2 *>(&Bs[rr * LDA2 + 4 * q]);
                         dst[0] = make_float2(v.x, v.y);
                         dst[1] = make_float2(v.z, v.w);
@@ -694,13 +715,12 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(GemmArgs a, float *__res
         if (!first) __syncthreads();
         first = false;
         {
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             static_for<0, NX>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 const int idx = tid + 256 * u;
                 if (idx < WK2 * QX) {
                     const int kk = idx / QX, q = idx - kk * QX;
-                    *reinterpret_cast<float4 *>(&Xs[kk * LDX2 + 4 * q]) = (kk < crow && q < qx) ? rx[u] : z;
+                    *reinterpret_cast<float4 *>(&Xs[kk * LDX2 + 4 * q]) = keep_if(kk < crow && q < qx, rx[u]);
                 }
             });
             static_for<0, NG>([&](auto uc) {
@@ -708,7 +728,7 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(GemmArgs a, float *__res
                 const int idx = tid + 256 * u;
                 if (idx < WK2 * QG) {
                     const int kk = idx / QG, q = idx - kk * QG;
-                    *reinterpret_cast<float4 *>(&Gs[kk * LDB2 + 4 * q]) = (kk < crow && q < qg) ? rg[u] : z;
+                    *reinterpret_cast<float4 *>(&Gs[kk * LDB2 + 4 * q]) = keep_if(kk < crow && q < qg, rg[u]);
                 }
             });
         }
