@@ -124,6 +124,9 @@ const char *kge_version(void);
  *   "counts_krel": dense TransE sign-count path: group b sends its relation-side records to virtual copy b % counts_krel of the
  *                     relation rows while they are ordered, the segmented sum folds the copies back (hub rows otherwise
  *                     serialise the LDS atomics of the bucketing kernels); a power of two, default 4 (measured best of 1..64), 1 = off
+ *   "transr_dgrad_records" / "transr_dgrad_records_min": TransR backward w.r.t. the entity rows: 1 (default) = the rows of
+ *                     G . M_r^T are stored as float records and summed per entity by the record sort + segmented sum from
+ *                     `_min` (default 32768) projected rows per step on; 0 = fp32 atomics always
  *   "inv_carry": 0 = recompute that table in front of every emit launch (test hook; default 1)
  *   "record_emit_event": 1 = record an event behind every TransE emit launch (kge_stream_wait_emit); default 0
  *   "pair_counts":       1 (default) = TransH / TransD steps of at least float_records_min entity-side rows (widths that are

@@ -230,6 +230,8 @@ int kge_set_option(const char *name, INT value) {
     if (n == "hub_copies") { engine().hub_copies = value != 0; return KGE_OK; }
     if (n == "pair_counts") { engine().pair_counts = value != 0; return KGE_OK; }
     if (n == "record_emit_event") { engine().record_emit_event = value != 0; return KGE_OK; }
+    if (n == "transr_dgrad_records") { engine().transr_dgrad_records = value != 0; return KGE_OK; }
+    if (n == "transr_dgrad_records_min") { engine().transr_dgrad_records_min = value; return KGE_OK; }
     if (n == "transr_lean") { engine().transr_lean = value != 0; return KGE_OK; }
     if (n == "pair_counts_min_neg") { engine().pair_counts_min_neg = (int)value; return KGE_OK; }
     if (n == "lp_v1") { engine().lp_v1 = value != 0; return KGE_OK; }

@@ -71,6 +71,8 @@ struct Engine {
     int float_records = 1;              // TransH / TransD (and TransE without counts): record + segmented-sum path instead of fp32 atomics
     int64_t float_records_min = 1 << 16; // ... from this many gradient rows per step (below it the atomic kernel alone is quicker)
     int64_t index_device_min = int64_t(1) << 22;  // training sets from this many lines on are indexed on the device (index_build.hip); < 0 = never
+    int transr_dgrad_records = 1;      // TransR dgrad: entity-gradient rows as float records + segmented sum instead of fp32 atomics ...
+    int64_t transr_dgrad_records_min = 1 << 15;   // ... from this many (scored triple, side) slots per step
     int transr_lean = 1;        // TransR vector stage: the float4-per-lane kernel that also zero-fills GP (0 = generic fwdbwd_kernel + memset)
     int pair_counts = 1;        // TransH / TransD: int8 sign records keyed by (entity, relation) + per-pair backward (pairs.hip) instead of float records
     int pair_counts_min_neg = 0;   // ... from this many negatives per positive; 0 = the measured cross-over (TransH 5, TransD 3)

@@ -94,9 +94,10 @@ int ensure_work(int64_t slots, int64_t dr, int64_t R) {
 // ---------------------------------------------------------------------------------------------
 __global__ void prep_kernel(const int32_t *__restrict__ bh, const int32_t *__restrict__ bt, const int32_t *__restrict__ br,
                             long long n_pos, long long n_neg, long long stride, int negative_rel, int R,
-                            int32_t *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ job_ent) {
+                            int32_t *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ job_ent, int32_t *__restrict__ rec_dst) {
     const long long total = 2 * n_pos * (1 + n_neg);
     for (long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += (long long)gridDim.x * blockDim.x) {
+        if (rec_dst) rec_dst[slot] = -1;      // (dgrad's record mode: positions that no tile covers -- the alias slots -- carry no record)
         const long long s = slot >> 1;
         const int side = (int)(slot & 1);
         const long long k = s / n_pos, b = s - k * n_pos;
@@ -275,6 +276,11 @@ struct GemmArgs {
     float *g_ent;           // [E, De]
     const int32_t *sorted_slots, *job_ent, *bucket_start, *tile_rel, *tile_row0, *n_tiles;
     int De, Dr;
+    // dgrad, large steps: the output row of sorted job position p is STORED as float record p (rec_out[p * De ..]) with its entity
+    // in rec_dst[p], and summed per entity afterwards by the float-record sort + segmented sum (transe_counts.hip) -- memory-side
+    // fp32 atomics run at ~1.1 TB/s whatever their shape, and 82 MB of them per step were a third of the dgrad kernel
+    float *rec_out;
+    int32_t *rec_dst;
 };
 
 template <int MODE>
@@ -597,6 +603,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // t
         if (n_live > 0) gemm2_mfma_block<MODE, NT, RT2>(As, Bs, acc, wave, lane);
     }
 #undef KGE_LOAD_CHUNK
+    if (MODE == GEMM_DGRAD && a.rec_out && blockIdx.y == 0 && tid < rows) a.rec_dst[row0 + tid] = s_ent[tid];
 #pragma unroll
     for (int s2 = 0; s2 < RT2; s2++) {
         if ((4 * s2 + wave) * 16 >= rows) continue;
@@ -609,6 +616,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // t
                     const int row = (4 * s2 + wave) * 16 + 4 * (lane >> 4) + v;
                     if (row < rows) {
                         if (MODE == GEMM_PROJECT) a.P[(long long)s_slot[row] * a.Dr + j0 + j] = acc[s2][t][v];
+                        else if (a.rec_out) a.rec_out[(long long)(row0 + row) * a.De + j0 + j] = acc[s2][t][v];
                         else __builtin_amdgcn_global_atomic_fadd_f32(
                                 (__attribute__((address_space(1))) float *)(a.g_ent + (long long)s_ent[row] * a.De + j0 + j), acc[s2][t][v]);
                     }
@@ -746,18 +754,30 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(GemmArgs a, float *__res
             n_crow = min(WK2, n_rows - nc);
             KGE_WLOAD(n_first, n_crow)
         }
+        {   // the chunk's WK2 / 4 k-steps, operand reads of step s+1 in front of the MFMAs of step s (see gemm2_mfma_block)
+            constexpr int STEPS = WK2 / 4;
+            const float *xa[2];
 #pragma unroll
-        for (int ks = 0; ks < WK2; ks += 4) {
-            const int kk = ks + (lane >> 4);
-            float av[2];
+            for (int s2 = 0; s2 < 2; s2++) xa[s2] = Xs + (lane >> 4) * LDX2 + min(wave + 4 * s2, WH2 - 1) * 16 + (lane & 15);   // A[i][k] = X[row k][i]
+            const float *gb = Gs + (lane >> 4) * LDB2 + (lane & 15);                                                            // B[k][j] = GP[row k][j]
+            float av[2][2], bv[2][NT2];
+            auto fetch = [&](int buf, int st) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) av[s2] = Xs[kk * LDX2 + min(wave + 4 * s2, WH2 - 1) * 16 + (lane & 15)];   // A[i][k] = X[row k][i]
+                for (int s2 = 0; s2 < 2; s2++) av[buf][s2] = xa[s2][4 * st * LDX2];
 #pragma unroll
-            for (int t2 = 0; t2 < NT2; t2++) {
-                const float bv = Gs[kk * LDB2 + t2 * 16 + (lane & 15)];   // B[k][j] = GP[row k][j]
+                for (int t2 = 0; t2 < NT2; t2++) bv[buf][t2] = gb[4 * st * LDB2 + t2 * 16];
+            };
+            fetch(0, 0);
+            static_for<0, STEPS>([&](auto sc) {
+                constexpr int st = decltype(sc)::value;
+                constexpr int cur = st & 1;
+                if constexpr (st + 1 < STEPS) fetch(cur ^ 1, st + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s2 = 0; s2 < 2; s2++) acc[s2][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv, acc[s2][t2], 0, 0, 0);
-            }
+                for (int t2 = 0; t2 < NT2; t2++)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; s2++) acc[s2][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][s2], bv[cur][t2], acc[s2][t2], 0, 0, 0);
+            });
         }
         if (!more) break;
         t = nt_; c0 = nc; row_first = n_first; crow = n_crow; rel = n_rel; rows_t = n_rows;
@@ -785,10 +805,16 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     if (rc) return rc;
     int blocks = (int)((slots + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, stream, d_h, d_t, d_r, (long long)n_pos, (long long)n_neg,
-                       (long long)stride, (int)m.negative_rel, (int)R, g_w.keys, g_w.vals, g_w.job_ent);
     // v2 kernels (16x16x4 MFMA, 128-row tiles): dims multiples of 4 up to 208, one workgroup covers all columns
     const bool v2 = De % 4 == 0 && Dr % 4 == 0 && De >= 4 && Dr >= 4 && De <= LDB2 && Dr <= LDB2 && engine().transr_v1 != 1;
+    // dgrad's entity-gradient rows as float records + segmented sum instead of atomics: from 32 768 slots on (below that the
+    // reduction's four launches cost more than the atomics do), entity row spaces the record sort handles
+    float *drec = nullptr;
+    int32_t *ddst = nullptr;
+    const bool dgrad_records = v2 && engine().transr_dgrad_records && slots >= engine().transr_dgrad_records_min;
+    if (dgrad_records && (rc = float_records_workspace(slots, De, drec, ddst))) return rc;
+    hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, stream, d_h, d_t, d_r, (long long)n_pos, (long long)n_neg,
+                       (long long)stride, (int)m.negative_rel, (int)R, g_w.keys, g_w.vals, g_w.job_ent, ddst);
     if (R + 1 <= kRelBins && !engine().counts_force_sort) {
         // two-launch counting sort by relation; bucket starts and the tile map come with it
         if (!g_w.rel_hist) {
@@ -814,6 +840,7 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     ga.sorted_slots = g_w.vals2; ga.job_ent = g_w.job_ent; ga.bucket_start = g_w.bucket_start;
     ga.tile_rel = g_w.tile_rel; ga.tile_row0 = g_w.tile_row0; ga.n_tiles = g_w.n_tiles;
     ga.De = De; ga.Dr = Dr;
+    ga.rec_out = drec; ga.rec_dst = ddst;
     const unsigned max_tiles = (unsigned)(slots / (v2 ? RW2 : 32) + R + 1);
     // sparse buckets (config #4's auto batch: 46 rows per relation, ~one tile per relation, fewer tiles than CUs): two column
     // blocks of 7 tiles per row tile instead of one of 13
@@ -831,6 +858,11 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
         if (De <= 112) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 7>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
         else if (split_cols) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 7>), dim3(max_tiles, (De + 111) / 112), dim3(256), 0, stream, ga);
         else hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 13>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
+        if (dgrad_records) {
+            FloatRowSpace rs = {};
+            rs.g_ent = grads[0]; rs.E = m.ent_total; rs.R = 0; rs.hub_base = m.ent_total; rs.hub_rows = 1; rs.rows = m.ent_total;
+            if ((rc = float_records_reduce(slots, De, rs, stream))) return rc;
+        }
         // the all-output-tiles wgrad (full 13 x 13 tile grid only) pays one 160 kB flush per relation change: only with
         // well-filled buckets (measured: 316 vs 400 us at 574 rows per relation, 131 vs 77 us at 46)
         const bool full_grid = De > 192 && Dr > 192;
