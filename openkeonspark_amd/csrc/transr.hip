@@ -154,8 +154,12 @@ __global__ __launch_bounds__(1024) void bounds_kernel(const int32_t *__restrict_
 // The order inside a bucket is whatever the cursors hand out (projection and dgrad are per-row; wgrad sums a bucket's rows
 // in a different order from run to run, as its atomics already did).
 // ---------------------------------------------------------------------------------------------
-constexpr int kRelBins = 4096;        // R + 1 must fit the LDS histogram
+constexpr int kRelBins = 4096;        // (R + 1) * kRelSub must fit the LDS histogram
 constexpr int kRelTile = 4096;        // jobs per workgroup of the scatter
+// Every relation is counted in kRelSub adjacent bins, a job taking the bin of its thread (tid % kRelSub): the Zipf-head relation of a
+// skewed graph holds a sixth of the jobs and its one LDS counter serialised the wave's atomics (SQ_LDS_BANK_CONFLICT 75-91 % of the
+// LDS cycles of both kernels).  The sub-bins of a relation are adjacent in the sorted order, so together they are its bucket.
+constexpr int kRelSub = 4;
 
 __global__ __launch_bounds__(256) void rel_count_kernel(const int32_t *__restrict__ keys, int J, int bins, int32_t *__restrict__ hist,
                                                         int32_t *__restrict__ next_pair) {
@@ -164,7 +168,8 @@ __global__ __launch_bounds__(256) void rel_count_kernel(const int32_t *__restric
         for (int i = threadIdx.x; i < 2 * kRelBins; i += 256) next_pair[i] = 0;
     for (int i = threadIdx.x; i < bins; i += 256) h[i] = 0;
     __syncthreads();
-    for (int i = blockIdx.x * kRelTile + threadIdx.x; i < min(J, (blockIdx.x + 1) * kRelTile); i += 256) atomicAdd(&h[keys[i]], 1);
+    for (int i = blockIdx.x * kRelTile + threadIdx.x; i < min(J, (blockIdx.x + 1) * kRelTile); i += 256)
+        atomicAdd(&h[keys[i] * kRelSub + (threadIdx.x & (kRelSub - 1))], 1);
     __syncthreads();
     for (int i = threadIdx.x; i < bins; i += 256) if (h[i]) atomicAdd(&hist[i], h[i]);
 }
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256) void rel_scatter_kernel(const int32_t *__restr
                                                           int32_t *__restrict__ sorted_vals, int32_t *__restrict__ bucket_start,
                                                           int32_t *__restrict__ tile_rel, int32_t *__restrict__ tile_row0,
                                                           int32_t *__restrict__ n_tiles, int tile_shift) {
-    const int bins = R + 1;
+    const int bins = (R + 1) * kRelSub;
     __shared__ int start[kRelBins + 1];      // exclusive scan of the histogram
     __shared__ int cnt[kRelBins];            // this tile's histogram, then its base per bin
     __shared__ int part[256];
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256) void rel_scatter_kernel(const int32_t *__restr
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const int i = blockIdx.x * kRelTile + threadIdx.x + 256 * k;
-        key[k] = i < J ? keys[i] : -1;
+        key[k] = i < J ? keys[i] * kRelSub + (int)(threadIdx.x & (kRelSub - 1)) : -1;
         rank[k] = key[k] >= 0 ? atomicAdd(&cnt[key[k]], 1) : 0;
     }
     __syncthreads();
@@ -216,11 +221,16 @@ __global__ __launch_bounds__(256) void rel_scatter_kernel(const int32_t *__restr
     }
     if (blockIdx.x != 0) return;
     // workgroup 0: bucket starts (bucket_start[r] = first position with key >= r, r = 0 .. R+1) and the tile map
-    for (int r = threadIdx.x; r <= R + 1; r += 256) bucket_start[r] = r <= R ? start[r] : J;
+    for (int r = threadIdx.x; r <= R + 1; r += 256) bucket_start[r] = r <= R ? start[r * kRelSub] : J;
     const int tile_rows = 1 << tile_shift;
+    // relation r's bucket = its kRelSub sub-bins; thread t maps the relations t*RPT .. t*RPT + RPT-1
+    constexpr int RPT = PER / kRelSub;
     int tiles_mine = 0;
 #pragma unroll
-    for (int k = 0; k < PER; k++) { const int r = threadIdx.x * PER + k; if (r < R) tiles_mine += (local[k] + tile_rows - 1) >> tile_shift; }
+    for (int k = 0; k < RPT; k++) {
+        const int r = threadIdx.x * RPT + k;
+        if (r < R) tiles_mine += (start[(r + 1) * kRelSub] - start[r * kRelSub] + tile_rows - 1) >> tile_shift;
+    }
     __syncthreads();
     part[threadIdx.x] = tiles_mine;
     __syncthreads();
@@ -233,10 +243,10 @@ __global__ __launch_bounds__(256) void rel_scatter_kernel(const int32_t *__restr
     int tix = part[threadIdx.x] - tiles_mine;
     if (threadIdx.x == 255) n_tiles[0] = part[255];
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const int r = threadIdx.x * PER + k;
+    for (int k = 0; k < RPT; k++) {
+        const int r = threadIdx.x * RPT + k;
         if (r < R)
-            for (int row = start[r]; row < start[r] + local[k]; row += tile_rows) { tile_rel[tix] = r; tile_row0[tix] = row; tix++; }
+            for (int row = start[r * kRelSub]; row < start[(r + 1) * kRelSub]; row += tile_rows) { tile_rel[tix] = r; tile_row0[tix] = row; tix++; }
     }
 }
 
@@ -636,7 +646,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // t
 // loop.  A relation whose whole bucket lies inside the span has one owner: its matrix gradient is stored, not added with
 // atomics (the accumulator is zero).
 constexpr int SPAN2 = 4;
-constexpr int WK2 = 16;                 // rows per staged chunk (4 k-steps)
+constexpr int WK2 = 32;                 // rows per staged chunk (8 k-steps: half the barriers of 16-row chunks; 41 KB of LDS, two workgroups per CU)
 constexpr int WH2 = 7;                  // output row tiles per half
 constexpr int LDX2 = WH2 * 16;          // [row k][i] stride of the staged X half: 112 = 16 mod 32 banks
 
@@ -815,7 +825,7 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     if (dgrad_records && (rc = float_records_workspace(slots, De, drec, ddst))) return rc;
     hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, stream, d_h, d_t, d_r, (long long)n_pos, (long long)n_neg,
                        (long long)stride, (int)m.negative_rel, (int)R, g_w.keys, g_w.vals, g_w.job_ent, ddst);
-    if (R + 1 <= kRelBins && !engine().counts_force_sort) {
+    if ((R + 1) * kRelSub <= kRelBins && !engine().counts_force_sort) {
         // two-launch counting sort by relation; bucket starts and the tile map come with it
         if (!g_w.rel_hist) {
             if ((rc = grow(g_w.rel_hist, 4 * (size_t)kRelBins, "transr relation histogram"))) return rc;
@@ -824,7 +834,7 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
         int32_t *pair = g_w.rel_hist + (g_w.rel_parity ? 2 * kRelBins : 0), *other = g_w.rel_hist + (g_w.rel_parity ? 0 : 2 * kRelBins);
         g_w.rel_parity ^= 1;
         const unsigned tiles = (unsigned)((slots + kRelTile - 1) / kRelTile);
-        hipLaunchKernelGGL(rel_count_kernel, dim3(tiles), dim3(256), 0, stream, g_w.keys, (int)slots, (int)R + 1, pair, other);
+        hipLaunchKernelGGL(rel_count_kernel, dim3(tiles), dim3(256), 0, stream, g_w.keys, (int)slots, ((int)R + 1) * kRelSub, pair, other);
         hipLaunchKernelGGL(rel_scatter_kernel, dim3(tiles), dim3(256), 0, stream, g_w.keys, g_w.vals, (int)slots, (int)R, pair,
                            pair + kRelBins, g_w.vals2, g_w.bucket_start, g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, v2 ? 7 : 5);
     } else {
