@@ -39,7 +39,6 @@ namespace {
 struct TrWork {
     float *P = nullptr, *GP = nullptr;
     int32_t *keys = nullptr, *keys2 = nullptr, *vals = nullptr, *vals2 = nullptr, *job_ent = nullptr;
-    int32_t *sorted_ent = nullptr;    // entity of the job at each SORTED position (= job_ent[sorted slot]): one dependent load less in every GEMM kernel
     int32_t *bucket_start = nullptr;  // [R+2]
     int32_t *tile_rel = nullptr, *tile_row0 = nullptr, *n_tiles = nullptr;
     int32_t *rel_hist = nullptr;      // two alternating pairs of [kRelBins] bucket sizes + [kRelBins] scatter cursors
@@ -68,7 +67,6 @@ int ensure_work(int64_t slots, int64_t dr, int64_t R) {
         if ((rc = grow(g_w.vals, (size_t)s, "transr vals"))) return rc;
         if ((rc = grow(g_w.vals2, (size_t)s, "transr vals2"))) return rc;
         if ((rc = grow(g_w.job_ent, (size_t)s, "transr job_ent"))) return rc;
-        if ((rc = grow(g_w.sorted_ent, (size_t)s, "transr sorted_ent"))) return rc;
         size_t bytes = 0;
         (void)rocprim::radix_sort_pairs(nullptr, bytes, g_w.keys, g_w.keys2, g_w.vals, g_w.vals2, (size_t)s, 0, 32, nullptr);
         if (bytes > g_w.sort_tmp_bytes) {
@@ -178,8 +176,7 @@ __global__ __launch_bounds__(256) void rel_count_kernel(const int32_t *__restric
 
 __global__ __launch_bounds__(256) void rel_scatter_kernel(const int32_t *__restrict__ keys, const int32_t *__restrict__ vals, int J, int R,
                                                           int32_t *__restrict__ hist, int32_t *__restrict__ cursor,
-                                                          int32_t *__restrict__ sorted_vals, const int32_t *__restrict__ job_ent,
-                                                          int32_t *__restrict__ sorted_ent, int32_t *__restrict__ bucket_start,
+                                                          int32_t *__restrict__ sorted_vals, int32_t *__restrict__ bucket_start,
                                                           int32_t *__restrict__ tile_rel, int32_t *__restrict__ tile_row0,
                                                           int32_t *__restrict__ n_tiles, int tile_shift) {
     const int bins = (R + 1) * kRelSub;
@@ -220,11 +217,7 @@ __global__ __launch_bounds__(256) void rel_scatter_kernel(const int32_t *__restr
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const int i = blockIdx.x * kRelTile + threadIdx.x + 256 * k;
-        if (key[k] >= 0) {
-            const int pos = cnt[key[k]] + rank[k], slot = vals[i];
-            sorted_vals[pos] = slot;
-            sorted_ent[pos] = job_ent[slot];
-        }
+        if (key[k] >= 0) sorted_vals[cnt[key[k]] + rank[k]] = vals[i];
     }
     if (blockIdx.x != 0) return;
     // workgroup 0: bucket starts (bucket_start[r] = first position with key >= r, r = 0 .. R+1) and the tile map
@@ -292,7 +285,6 @@ struct GemmArgs {
     float *P;               // [slots, Dr]
     float *g_ent;           // [E, De]
     const int32_t *sorted_slots, *job_ent, *bucket_start, *tile_rel, *tile_row0, *n_tiles;
-    const int32_t *sorted_ent;    // job_ent[sorted_slots[p]] at position p (written with the sort)
     int De, Dr;
     // dgrad, large steps: the output row of sorted job position p is STORED as float record p (rec_out[p * De ..]) with its entity
     // in rec_dst[p], and summed per entity afterwards by the float-record sort + segmented sum (transe_counts.hip) -- memory-side
@@ -544,10 +536,9 @@ __global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // t
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < RW2) {
-        const int pos = row0 + min(tid, rows - 1);            // padding rows repeat the last live row (never stored)
-        int sl = a.sorted_slots[pos];
+        int sl = a.sorted_slots[row0 + min(tid, rows - 1)];   // padding rows repeat the last live row (never stored)
         s_slot[tid] = sl;
-        s_ent[tid] = a.sorted_ent ? a.sorted_ent[pos] : a.job_ent[sl];
+        s_ent[tid] = a.job_ent[sl];
     }
     __syncthreads();
     const float *M = a.mat + (long long)r * a.De * a.Dr;
@@ -655,7 +646,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // t
 // loop.  A relation whose whole bucket lies inside the span has one owner: its matrix gradient is stored, not added with
 // atomics (the accumulator is zero).
 constexpr int SPAN2 = 4;
-constexpr int WK2 = 16;                 // rows per staged chunk (4 k-steps; 32-row chunks measured equal and spill)
+constexpr int WK2 = 32;                 // rows per staged chunk (8 k-steps: half the barriers of 16-row chunks; 41 KB of LDS, two workgroups per CU)
 constexpr int WH2 = 7;                  // output row tiles per half
 constexpr int LDX2 = WH2 * 16;          // [row k][i] stride of the staged X half: 112 = 16 mod 32 banks
 
@@ -692,8 +683,7 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(GemmArgs a, float *__res
             constexpr int u = decltype(uc)::value;                                                            \
             const int idx = min(tid + 256 * u, WK2 * QX - 1);                                                 \
             const int kk = idx / QX, q = idx - kk * QX;                                                       \
-            const int pos_ = (row_first_) + min(kk, (crow_) - 1);                                             \
-            const int e = a.sorted_ent ? a.sorted_ent[pos_] : a.job_ent[a.sorted_slots[pos_]];                \
+            const int e = a.job_ent[a.sorted_slots[(row_first_) + min(kk, (crow_) - 1)]];                     \
             rx[u] = *reinterpret_cast<const float4 *>(a.ent + (long long)e * a.De + i0 + 4 * min(q, qx - 1)); \
         });                                                                                                   \
         static_for<0, NG>([&](auto uc) {                                                                      \
@@ -835,8 +825,7 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     if (dgrad_records && (rc = float_records_workspace(slots, De, drec, ddst))) return rc;
     hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, stream, d_h, d_t, d_r, (long long)n_pos, (long long)n_neg,
                        (long long)stride, (int)m.negative_rel, (int)R, g_w.keys, g_w.vals, g_w.job_ent, ddst);
-    const bool counting_sort = (R + 1) * kRelSub <= kRelBins && !engine().counts_force_sort;
-    if (counting_sort) {
+    if ((R + 1) * kRelSub <= kRelBins && !engine().counts_force_sort) {
         // two-launch counting sort by relation; bucket starts and the tile map come with it
         if (!g_w.rel_hist) {
             if ((rc = grow(g_w.rel_hist, 4 * (size_t)kRelBins, "transr relation histogram"))) return rc;
@@ -847,7 +836,7 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
         const unsigned tiles = (unsigned)((slots + kRelTile - 1) / kRelTile);
         hipLaunchKernelGGL(rel_count_kernel, dim3(tiles), dim3(256), 0, stream, g_w.keys, (int)slots, ((int)R + 1) * kRelSub, pair, other);
         hipLaunchKernelGGL(rel_scatter_kernel, dim3(tiles), dim3(256), 0, stream, g_w.keys, g_w.vals, (int)slots, (int)R, pair,
-                           pair + kRelBins, g_w.vals2, g_w.job_ent, g_w.sorted_ent, g_w.bucket_start, g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, v2 ? 7 : 5);
+                           pair + kRelBins, g_w.vals2, g_w.bucket_start, g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, v2 ? 7 : 5);
     } else {
         size_t tmp = g_w.sort_tmp_bytes;
         rc = hip_check(rocprim::radix_sort_pairs(g_w.sort_tmp, tmp, g_w.keys, g_w.keys2, g_w.vals, g_w.vals2, (size_t)slots, 0,
@@ -861,7 +850,6 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     ga.sorted_slots = g_w.vals2; ga.job_ent = g_w.job_ent; ga.bucket_start = g_w.bucket_start;
     ga.tile_rel = g_w.tile_rel; ga.tile_row0 = g_w.tile_row0; ga.n_tiles = g_w.n_tiles;
     ga.De = De; ga.Dr = Dr;
-    ga.sorted_ent = counting_sort ? g_w.sorted_ent : nullptr;
     ga.rec_out = drec; ga.rec_dst = ddst;
     const unsigned max_tiles = (unsigned)(slots / (v2 ? RW2 : 32) + R + 1);
     // sparse buckets (config #4's auto batch: 46 rows per relation, ~one tile per relation, fewer tiles than CUs): two column
