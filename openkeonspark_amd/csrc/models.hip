@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void transe_emit_kernel(FbArgs a) {
                         } else {                    // new relation vector: -unit*s ; h gets -s, t gets +s
 #pragma unroll
                             for (int q = 0; q < Q; q++) { const uint32_t ns = pneg8(sg[u][q]); rec[q] = ns; Ah[q] = padd8(Ah[q], ns); At[q] = padd8(At[q], sg[u][q]); }
-                            dest = (long long)a.ent_total + (long long)(b % a.krel) * a.rel_total + row[u];
+                            dest = (long long)a.ent_total + (long long)((int)b & (a.krel - 1)) * a.rel_total + row[u];
                         }
                         store_record<L, Q>(a, tm.lane, m, rec);
                     }
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void transe_emit_kernel(FbArgs a) {
         if (tm.lane == 0) {
             a.dst[b] = cnt > 0 ? (int32_t)h : -1;
             a.dst[a.n_pos + b] = cnt > 0 ? (int32_t)t : -1;
-            a.dst[2 * a.n_pos + b] = cnt > 0 ? (int32_t)(a.ent_total + (int)(b % a.krel) * a.rel_total + r) : -1;
+            a.dst[2 * a.n_pos + b] = cnt > 0 ? (int32_t)(a.ent_total + ((int)b & (a.krel - 1)) * a.rel_total + r) : -1;
         }
     }
     finish_loss<TEAMS>(a, red, lsum, tm.lane, team_in_block);
@@ -276,6 +276,7 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
     float lsum = 0.f;
     for (long long b = (long long)blockIdx.x * TEAMS + team_in_block; b < a.n_pos; b += (long long)gridDim.x * TEAMS) {
         const int h = a.bh[b], t = a.bt[b], r = a.br[b];
+        const int rel_row0 = a.ent_total + ((int)b & (a.krel - 1)) * a.rel_total;   // this group's virtual copy of the relation rows (krel: a power of two)
         // ---- negatives' ids: one per lane (first round), classified once ----
         int my_code = 0, my_row = 0;
         float my_f = 0.f;
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
                             Ar_lo[q] += s_lo * kr; Ar_hi[q] += s_hi * kr;
                         }
                         store_record<L, Q>(a, lane, m, rec);
-                        if (lane == kk + u) my_dst = code[u] == 2 ? a.ent_total + (int)(b % a.krel) * a.rel_total + row[u] : row[u];
+                        if (lane == kk + u) my_dst = code[u] == 2 ? rel_row0 + row[u] : row[u];
                     }
                 }
             }
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
         if (lane == 0) {
             a.dst[b] = cnt > 0 ? (int32_t)h : -1;
             a.dst[a.n_pos + b] = cnt > 0 ? (int32_t)t : -1;
-            a.dst[2 * a.n_pos + b] = cnt > 0 ? (int32_t)(a.ent_total + (int)(b % a.krel) * a.rel_total + r) : -1;
+            a.dst[2 * a.n_pos + b] = cnt > 0 ? (int32_t)(rel_row0 + r) : -1;
         }
     }
     finish_loss<TEAMS>(a, red, lsum, lane, team_in_block);
@@ -633,7 +634,8 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
     a.D = m.ent_dim; a.margin = m.margin; a.unit = 1.0f / (float)denom;
     a.loss_partials = e.dev.loss_partials;
     a.negative_rel = m.negative_rel;
-    a.rec = rec; a.dst = dst; a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total; a.krel = krel < 1 ? 1 : krel;
+    a.rec = rec; a.dst = dst; a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total; a.krel = 1;
+    while (a.krel * 2 <= krel) a.krel *= 2;      // a power of two: the kernels take b & (krel - 1)
     const int D = a.D;
     if (D % 4 == 0 && D <= 64) launch_emit<16, 4>(a, d_loss, stream);
     else if (D <= 16) launch_emit<16, 1>(a, d_loss, stream);
