@@ -345,21 +345,6 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
 #pragma unroll
         for (int q = 0; q < Q; q++) { Ah_lo[q] = 0; Ah_hi[q] = 0; At_lo[q] = 0; At_hi[q] = 0; Ar_lo[q] = 0; Ar_hi[q] = 0; }
         int cnt = 0;
-        // Record stores are DEFERRED by one iteration.  Loads and stores share one in-order counter (s_waitcnt vmcnt): a record
-        // stored at the end of iteration i sits in front of iteration i+1's row gathers in that order, and the wait for the rows
-        // also waits for the store's round trip (with every hinge active -- the first steps of a run -- the kernel took 143 us
-        // against 115 with a third active, whatever the records' size or the active path's instruction count).  The records of
-        // iteration i are therefore issued in iteration i+1 right AFTER its rows have arrived: they have that iteration's whole
-        // scoring phase and the next gather's latency to complete in.  Pending state: the K record words, the first slot and a mask.
-        uint32_t pend_rec[K][Q];
-        int pend_slot0 = 0;
-        unsigned pend_mask = 0u;
-        auto flush_pending = [&]() {
-#pragma unroll
-            for (int u = 0; u < K; u++)
-                if (pend_mask & (1u << u)) store_record<L, Q>(a, lane, (long long)(pend_slot0 + u) * a.n_pos + b, pend_rec[u]);
-            pend_mask = 0u;
-        };
         for (int k0 = 0; k0 < (int)a.n_neg; k0 += L) {
             if (k0 > 0) {   // later rounds (n_neg > L): fetch and classify this round's ids
                 const int my_k = k0 + lane;
@@ -422,7 +407,6 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
                     if (code[u] == 0) apply(B0); else if (code[u] == 1) apply(B1); else apply(B2);
                     sc[u] = acc;
                 }
-                flush_pending();       // the previous iteration's records: this iteration's rows have arrived, nothing waits behind these stores
 #pragma unroll
                 for (int u = 0; u < K; u++) sc[u] = team_sum<L>(sc[u]);
 #pragma unroll
@@ -431,6 +415,7 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
                     const float v = p - sc[u] + a.margin;
                     if (v >= 0.f) {
                         cnt++; lsum += v;
+                        const long long m = (long long)(3 + k0 + kk + u) * a.n_pos + b;
                         uint32_t rec[Q];
                         // new head (0): dL/dx^ = -s, kept t gets +s, r gets -s;  new tail (1): +s, kept h gets -s, r gets -s;
                         // new relation vector (2): -s, h gets -s, t gets +s.  Branch-free: the three cases differ only in small
@@ -448,9 +433,7 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
                             At_lo[q] += s_lo * kt; At_hi[q] += s_hi * kt;
                             Ar_lo[q] += s_lo * kr; Ar_hi[q] += s_hi * kr;
                         }
-#pragma unroll
-                        for (int q = 0; q < Q; q++) pend_rec[u][q] = rec[q];
-                        pend_slot0 = 3 + k0 + kk; pend_mask |= 1u << u;
+                        store_record<L, Q>(a, lane, m, rec);
                         if (lane == kk + u) my_dst = code[u] == 2 ? rel_row0 + row[u] : row[u];
                     }
                 }
@@ -458,7 +441,6 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
             // destinations of this round's negatives: one store instruction for the whole round
             if (k0 + lane < (int)a.n_neg) a.dst[(long long)(3 + k0 + lane) * a.n_pos + b] = my_dst;
         }
-        flush_pending();
         if (cnt > 0) {
             uint32_t rh[Q], rt[Q], rr[Q];
             const s16x2 c2 = pack16(cnt, cnt);
