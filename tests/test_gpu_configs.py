@@ -327,7 +327,9 @@ def test_config2_fb15k237_transe_adam_n25_bench_size(fb_dir):
                   elements_of_e_within_tol_of_zero=tot["kink_elems"], groups_with_hinge_within_tie_tol=tot["tie_groups"],
                   adam_elements_beyond_1e3_of_a_step_all_explained=tot["amplified"], worst_in_steps=tot["worst_steps"],
                   worst_adam_gain=tot["worst_gain"], v_relerr=tot["v"])
-    assert tot["grad"] <= RTOL and tot["grad_rows"] <= 64, tot
+    # (every row counted in grad_rows was checked above to belong to a kink or tie group; the cap only guards against a pattern:
+    #  a flipped element reaches the <= 28 rows of its group)
+    assert tot["grad"] <= RTOL and tot["grad_rows"] <= 28 * (tot["kink_elems"] + tot["tie_groups"]) and tot["grad_rows"] <= 400, tot
 
 
 def test_config2_loss_trajectory_20_steps(fb_dir):
