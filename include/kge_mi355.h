@@ -256,6 +256,13 @@ int kge_forward_backward_sampled(const kge_model_desc *m, const float *const tab
                                  INT n_pos, INT n_neg, INT stride, INT denom,
                                  float *const grads[KGE_MAX_TABLES], float *d_loss, void *stream);
 
+/* The loss of a data-parallel TransE step, carried inside the int32 count image that the step reduce-scatters anyway (one
+ * collective less per step): d_limbs4 receives the four 16-bit limbs of llrint(loss * 2^32); after the SUM exchange
+ * kge_limbs_to_loss turns the summed limbs back into the summed loss.  Exact integer arithmetic: the result does not depend on
+ * the number of ranks or on the reduction order. */
+int kge_loss_to_limbs(const float *d_loss, int32_t *d_limbs4, void *stream);
+int kge_limbs_to_loss(const int32_t *d_limbs4, float *d_out, void *stream);
+
 /* GradientDescentOptimizer on the summed gradient: p -= lr*g; g = 0   (distribute_training.py:98) */
 int kge_sgd_update(float *d_p, float *d_g, int64_t n, float lr, void *stream);
 /* TF1 AdamOptimizer._apply_sparse_shared on the summed gradient (distribute_training.py:96): every

@@ -378,18 +378,25 @@ class Config(object):
         W = self.world_size
         names = list(self.trainModel.table_names)
         numels = [t.numel() for t in self._tables]
+        # PIECES: the flat buffer is cut into K consecutive segments, each of them exchanged and updated like a small data-parallel
+        # problem of its own (rank g owns the g-th W-th of every segment), so that the optimizer on piece k and its all-gather run
+        # while piece k+1 is still on the wire.  One piece for FB15k-237-sized tables (the exchange is latency-, not size-bound
+        # there); four from 64 MB of image on.  `dp_pieces` overrides (tests force 2 on a small graph).
+        image_bytes = sum(numels) * 4
+        K = int(getattr(self, "dp_pieces", 0)) or (4 if image_bytes >= (64 << 20) else 1)
         if self.use_counts:     # ent_embeddings then rel_embeddings, back to back: rows of one [(E+R), D] space
             D = self.hidden_size
-            chunk_rows = chunk_size(self.entTotal + self.relTotal, W, 4)
+            chunk_rows = chunk_size(self.entTotal + self.relTotal, W, 4 * K)
+            if chunk_rows * W == self.entTotal + self.relTotal:
+                chunk_rows += 4 * K        # at least one spare row at the end: the loss rides in it (train_step)
             chunk = chunk_rows * D
             offs = [0, numels[0]]
-            self._own_rows = (self.rank * chunk_rows, min((self.rank + 1) * chunk_rows, self.entTotal + self.relTotal))
         else:
             offs, off = [], 0
             for n in numels:
                 offs.append(off)
                 off += -(-n // 64) * 64
-            chunk = chunk_size(off, W, 4)
+            chunk = chunk_size(off + 4, W, 4 * K)     # (+ 4: a spare tail slot for the loss)
         total = chunk * W
         dev = self._tables[0].device
         flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -411,11 +418,22 @@ class Config(object):
                     slots[i] = v
         self._flat_p, self._flat_g, self._flat_m, self._flat_v = flat_p, flat_g, flat_m, flat_v
         self._chunk = chunk
-        self._own = (self.rank * chunk, (self.rank + 1) * chunk)
+        self._pieces = K
+        seg, own = total // K, chunk // K                     # elements per piece, and per (piece, rank)
+        # piece k: segment [k*seg, (k+1)*seg) of the flat buffers; this rank's share of it; where that share sits in the owned images
+        self._piece_seg = [(k * seg, (k + 1) * seg) for k in range(K)]
+        self._piece_own = [(k * seg + self.rank * own, k * seg + (self.rank + 1) * own) for k in range(K)]
+        self._own_len = own
         self._grads_own = torch.zeros(chunk, dtype=torch.float32, device=dev)
+        self._loss_tail = total - 1                           # spare element (no table reaches it) of the LAST rank's last piece
         if self.use_counts:
-            self._counts = torch.zeros((chunk_rows * W, self.hidden_size), dtype=torch.int32, device=dev)
+            rows_total = chunk_rows * W
+            seg_r, own_r = rows_total // K, chunk_rows // K
+            live = self.entTotal + self.relTotal
+            self._counts = torch.zeros((rows_total, self.hidden_size), dtype=torch.int32, device=dev)
             self._counts_own = torch.zeros((chunk_rows, self.hidden_size), dtype=torch.int32, device=dev)
+            self._piece_rows = [(min(k * seg_r + self.rank * own_r, live), min(k * seg_r + (self.rank + 1) * own_r, live)) for k in range(K)]
+            self._own_rows_len = own_r
         self._opt_state_synced = True
         self._refresh_pointers()
         if getattr(self, "gather_dtype", "fp32") == "bf16":
@@ -548,22 +566,25 @@ class Config(object):
         self._beta1_power = f(self._beta1_power * f(self.adam_beta1))
         self._beta2_power = f(self._beta2_power * f(self.adam_beta2))
 
-    def apply_gradients(self, own=False):
+    def apply_gradients(self, own=False, piece=0):
         """GradientDescentOptimizer / AdamOptimizer on the summed gradients (distribute_training.py:95-101).
         own=True (data-parallel): on this rank's chunk of the flat parameter buffer only, from its reduce-scattered
         gradient chunk."""
         st = self._stream()
-        if own:
-            lo, n = self._own[0], self._chunk
-            p, g = self._flat_p.data_ptr() + 4 * lo, self._grads_own.data_ptr()
+        if own:       # one piece of this rank's share (train_step's exchange loop calls it per piece and advances Adam once)
+            lo, hi = self._piece_own[piece]
+            n = hi - lo
+            if hi > self._loss_tail:
+                n -= 4                                        # the spare tail slot (it holds the loss, not a parameter)
+            p, g = self._flat_p.data_ptr() + 4 * lo, self._grads_own.data_ptr() + 4 * piece * self._own_len
             if self._adam:
                 _lib.check(self.lib.kge_adam_update(p, self._flat_m.data_ptr() + 4 * lo, self._flat_v.data_ptr() + 4 * lo, g, n,
                                                     float(self._adam_lr_t()), self.adam_beta1, self.adam_beta2,
                                                     self.adam_epsilon, st), self.lib)
-                self._adam_advance()
                 self._opt_state_synced = False
             else:
                 _lib.check(self.lib.kge_sgd_update(p, g, n, float(self.alpha), st), self.lib)
+            return
         elif self._adam:
             _lib.check(self.lib.kge_adam_update_tables(len(self._tables), self._tab_ptrs, self._adam_m_ptrs, self._adam_v_ptrs,
                                                        self._grad_ptrs, self._numel, float(self._adam_lr_t()), self.adam_beta1,
@@ -574,14 +595,60 @@ class Config(object):
                                                       float(self.alpha), st), self.lib)
         self.global_step += 1
 
+    def _dp_exchange(self, image, own_image, apply_piece, counts):
+        """The data-parallel part of a dense step: reduce-scatter of the gradient image, the optimizer on the owned share,
+        all-gather of the updated parameters -- piece by piece (see _setup_flat_buffers), every collective asynchronous, so
+        that piece k is updated and sent while piece k+1 is still being summed.  The loss needs no collective of its own: it
+        is added into a spare tail slot of the image (TransE's int32 count image: as four 16-bit limbs of a 2^-32 fixed-point
+        value, kge_loss_to_limbs), summed by the reduce-scatter like everything else, written by its owner -- the last rank --
+        into the spare tail slot of the parameter buffer, and reaches every rank with the all-gather."""
+        from .parallel import reduce_scatter_sum, all_gather_chunks
+        st, W, K = self._stream(), self.world_size, self._pieces
+        flat_img, flat_own = image.view(-1), own_image.view(-1)
+        per_seg, per_own = flat_img.numel() // K, flat_own.numel() // K
+        ride = flat_img.numel() >= 4 and (not counts or self.hidden_size >= 4)
+        last = self.rank == W - 1
+        if ride:
+            if counts:
+                _lib.check(self.lib.kge_loss_to_limbs(self._loss.data_ptr(), flat_img[flat_img.numel() - self.hidden_size:].data_ptr(), st), self.lib)
+            else:
+                flat_img[-1:].copy_(self._loss)
+        rs = [reduce_scatter_sum(flat_own[k * per_own:(k + 1) * per_own], flat_img[k * per_seg:(k + 1) * per_seg], self._pg, async_op=True)
+              for k in range(K)]
+        if not ride:
+            from .parallel import allreduce_sum
+            allreduce_sum([self._loss], self._pg)
+        ag = []
+        for k in range(K):
+            if rs[k] is not None:
+                rs[k].wait()
+            if ride and last and k == K - 1:      # the summed loss -> the parameter buffer's tail slot (before the all-gather of this piece)
+                if counts:
+                    _lib.check(self.lib.kge_limbs_to_loss(flat_own[flat_own.numel() - self.hidden_size:].data_ptr(),
+                                                          self._flat_p[self._loss_tail:].data_ptr(), st), self.lib)
+                else:
+                    self._flat_p[self._loss_tail:].copy_(flat_own[-1:])
+            apply_piece(k)
+            (slo, shi), (lo, hi) = self._piece_seg[k], self._piece_own[k]
+            ag.append(all_gather_chunks(self._flat_p[slo:shi], self._flat_p[lo:hi], self._pg, async_op=True))
+        image.zero_()
+        if self._adam:
+            self._adam_advance()
+        self.global_step += 1
+        for w in ag:
+            if w is not None:
+                w.wait()
+        if ride:
+            self._loss.copy_(self._flat_p[self._loss_tail:])
+
     def sync_optimizer_state(self):
         """Data-parallel Adam keeps m and v current on their owner only; gather them before they are read as whole tables
         (checkpoints)."""
         if self.world_size > 1 and self._adam and not self.sparse_rows and not getattr(self, "_opt_state_synced", True):
             from .parallel import all_gather_chunks
-            lo, hi = self._own
-            all_gather_chunks(self._flat_m, self._flat_m[lo:hi], self._pg)
-            all_gather_chunks(self._flat_v, self._flat_v[lo:hi], self._pg)
+            for (slo, shi), (lo, hi) in zip(self._piece_seg, self._piece_own):
+                all_gather_chunks(self._flat_m[slo:shi], self._flat_m[lo:hi], self._pg)
+                all_gather_chunks(self._flat_v[slo:shi], self._flat_v[lo:hi], self._pg)
             self._opt_state_synced = True
 
     def train_step(self, batch_h=None, batch_t=None, batch_r=None, batch_y=None, sync=True):
@@ -624,12 +691,7 @@ class Config(object):
                 self._flush_next_batch()               # (launched on its own if the step's path had no scatter kernel)
             if self.world_size > 1:
                 # int32 SUM is exact: rank g receives the summed counts of ITS rows, updates them, and the updated rows go round
-                from .parallel import reduce_scatter_sum, allreduce_sum, all_gather_chunks
-                reduce_scatter_sum(self._counts_own.view(-1), self._counts.view(-1), self._pg)
-                allreduce_sum([self._loss], self._pg)
-                self._counts.zero_()
-                self.apply_counts(denom, own=True)
-                all_gather_chunks(self._flat_p, self._flat_p[self._own[0]:self._own[1]], self._pg)
+                self._dp_exchange(self._counts, self._counts_own, lambda k: self.apply_counts(denom, own=True, piece=k), counts=True)
                 self.tables_changed()
                 self._refresh_shadow()
             else:
@@ -639,12 +701,7 @@ class Config(object):
             if batch_h is None and self.prefetch_sampling:
                 self._prefetch_next_batch(behind_emit=bool(self.lib.kge_pair_path_active(ctypes.byref(self._desc), n_pos, n_neg)))
             if self.world_size > 1:
-                from .parallel import reduce_scatter_sum, allreduce_sum, all_gather_chunks
-                reduce_scatter_sum(self._grads_own, self._flat_g, self._pg)
-                allreduce_sum([self._loss], self._pg)
-                self._flat_g.zero_()
-                self.apply_gradients(own=True)
-                all_gather_chunks(self._flat_p, self._flat_p[self._own[0]:self._own[1]], self._pg)
+                self._dp_exchange(self._flat_g, self._grads_own, lambda k: self.apply_gradients(own=True, piece=k), counts=False)
             else:
                 self.apply_gradients()
         self.trainModel.loss = self._loss
@@ -887,7 +944,7 @@ class Config(object):
             self.negative_ent + self.negative_rel, stride, denom, self._counts.data_ptr(),
             resid[0], resid[1], self._loss.data_ptr(), self._stream()), self.lib)
 
-    def apply_counts(self, denom, own=False):
+    def apply_counts(self, denom, own=False, piece=0):
         """Normalise-backward on the summed counts + SGD / TF1 Adam, both tables in one launch
         (distribute_training.py:95-101).  own=True (data-parallel): this rank's rows of the [(E+R), D] row space only,
         from its reduce-scattered chunk of the count image."""
@@ -895,12 +952,16 @@ class Config(object):
         lr = float(self._adam_lr_t()) if self._adam else float(self.alpha)
         m_ptrs = self._adam_m_ptrs if self._adam else None
         v_ptrs = self._adam_v_ptrs if self._adam else None
-        if own:
-            _lib.check(self.lib.kge_transe_apply_counts_range(
-                ctypes.byref(self._desc), self._tab_ptrs, m_ptrs, v_ptrs, self._counts_own.data_ptr(), self._grad_ptrs,
-                self._own_rows[0], self._own_rows[1], denom, 1 if self._adam else 0, lr, self.adam_beta1, self.adam_beta2,
-                self.adam_epsilon, st), self.lib)
+        if own:       # one piece of this rank's rows (the exchange loop advances Adam and the step counter once per step)
+            row_lo, row_hi = self._piece_rows[piece]
+            if row_hi > row_lo:
+                img = self._counts_own.data_ptr() + 4 * piece * self._own_rows_len * self.hidden_size
+                _lib.check(self.lib.kge_transe_apply_counts_range(
+                    ctypes.byref(self._desc), self._tab_ptrs, m_ptrs, v_ptrs, img, self._grad_ptrs,
+                    row_lo, row_hi, denom, 1 if self._adam else 0, lr, self.adam_beta1, self.adam_beta2,
+                    self.adam_epsilon, st), self.lib)
             self._opt_state_synced = not self._adam
+            return
         else:
             _lib.check(self.lib.kge_transe_apply_counts_tables(
                 ctypes.byref(self._desc), self._tab_ptrs, m_ptrs, v_ptrs, self._counts.data_ptr(), self._grad_ptrs, denom,

@@ -76,6 +76,8 @@ def _declare(L):
     L.kge_stream_wait_emit.argtypes = [vp]
     L.kge_pair_path_active.argtypes = [ctypes.POINTER(ModelDesc), i64, i64]
     L.kge_forward_backward_sampled.argtypes = [ctypes.POINTER(ModelDesc), tabs, vp, vp, vp, i64, i64, i64, i64, tabs, vp, vp]
+    L.kge_loss_to_limbs.argtypes = [vp, vp, vp]
+    L.kge_limbs_to_loss.argtypes = [vp, vp, vp]
     L.kge_sgd_update.argtypes = [vp, vp, i64, f32, vp]
     L.kge_adam_update.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp]
     L.kge_sgd_update_tables.argtypes = [i32, vp, vp, vp, f32, vp]

@@ -78,3 +78,35 @@ int launch_adam(float *p, float *m, float *v, float *g, int64_t n, float lr_t, f
 }
 
 }  // namespace kge
+
+// ---- the loss riding in the exchanges of a data-parallel step (Config.train_step) ------------------------------------------
+// A TransE step exchanges an INT32 count image, so the rank's loss travels in it as four 16-bit limbs of llrint(loss * 2^32):
+// the SUM reduce-scatter then adds the ranks' losses exactly (integers; up to 32 768 ranks before a limb overflows), and the
+// result does not depend on the number of ranks or the reduction order.  Losses are < 2^20 (a mean hinge is a few units).
+namespace kge {
+__global__ void loss_to_limbs_kernel(const float *__restrict__ loss, int32_t *__restrict__ limbs) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double x = (double)loss[0] * 4294967296.0;
+        long long v = x >= 0.0 ? (long long)(x + 0.5) : 0;       // the loss is a mean of hinges: never negative
+        for (int i = 0; i < 4; i++) limbs[i] = (int32_t)((v >> (16 * i)) & 0xFFFF);
+    }
+}
+__global__ void limbs_to_loss_kernel(const int32_t *__restrict__ limbs, float *__restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        long long v = 0;
+        for (int i = 0; i < 4; i++) v += (long long)limbs[i] << (16 * i);
+        out[0] = (float)((double)v / 4294967296.0);
+    }
+}
+}  // namespace kge
+
+extern "C" int kge_loss_to_limbs(const float *d_loss, int32_t *d_limbs4, void *stream) {
+    if (!d_loss || !d_limbs4) return kge::fail(KGE_ERR_BAD_ARG, "kge_loss_to_limbs: null argument");
+    hipLaunchKernelGGL(kge::loss_to_limbs_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_loss, d_limbs4);
+    return kge::hip_check(hipGetLastError(), "loss limbs launch");
+}
+extern "C" int kge_limbs_to_loss(const int32_t *d_limbs4, float *d_out, void *stream) {
+    if (!d_limbs4 || !d_out) return kge::fail(KGE_ERR_BAD_ARG, "kge_limbs_to_loss: null argument");
+    hipLaunchKernelGGL(kge::limbs_to_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_limbs4, d_out);
+    return kge::hip_check(hipGetLastError(), "loss limbs launch");
+}

@@ -79,12 +79,10 @@ def allreduce_sum(tensors, group=None):
         w.wait()
 
 
-# the name the callers of round 1 used
-allreduce_gradients = allreduce_sum
-
-
-def reduce_scatter_sum(out, inp, group=None):
-    """out[chunk] = sum over ranks of inp[rank*chunk : (rank+1)*chunk]; inp has world_size * out.numel() elements."""
+def reduce_scatter_sum(out, inp, group=None, async_op=False):
+    """out[chunk] = sum over ranks of inp[rank*chunk : (rank+1)*chunk]; inp has world_size * out.numel() elements.
+    async_op=True: returns the collective's Work (wait() makes the CURRENT STREAM wait, not the host), or None where the
+    exchange had to be staged through the host and is already complete (gloo test rigs)."""
     import torch
     import torch.distributed as dist
     if inp.numel() != out.numel() * dist.get_world_size(group):
@@ -93,12 +91,14 @@ def reduce_scatter_sum(out, inp, group=None):
         h_out = torch.empty(out.shape, dtype=out.dtype)
         dist.reduce_scatter_tensor(h_out, inp.cpu(), op=dist.ReduceOp.SUM, group=group)
         out.copy_(h_out)
-    else:
-        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
+        return None
+    work = dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return work if async_op else None
 
 
-def all_gather_chunks(out, inp, group=None):
-    """out = concatenation over ranks of inp (equal chunks).  `inp` may be this rank's slice of `out` (in place)."""
+def all_gather_chunks(out, inp, group=None, async_op=False):
+    """out = concatenation over ranks of inp (equal chunks).  `inp` may be this rank's slice of `out` (in place).
+    async_op: as reduce_scatter_sum."""
     import torch
     import torch.distributed as dist
     if out.numel() != inp.numel() * dist.get_world_size(group):
@@ -107,10 +107,12 @@ def all_gather_chunks(out, inp, group=None):
         h_out = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(h_out, inp.cpu(), group=group)
         out.copy_(h_out)
-    elif dist.get_backend(group) == "gloo":
+        return None
+    if dist.get_backend(group) == "gloo":
         dist.all_gather_into_tensor(out, inp.clone(), group=group)   # gloo copies chunk by chunk: keep input and output apart
-    else:
-        dist.all_gather_into_tensor(out, inp, group=group)
+        return None
+    work = dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
+    return work if async_op else None
 
 
 def exchange_counts(send_counts, group=None):

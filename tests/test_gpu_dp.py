@@ -12,7 +12,7 @@ from conftest import GOLDEN, ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=False, nbatches=10):
+def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=False, nbatches=10, pieces=0):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -33,11 +33,15 @@ def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=
     con.sparse_rows = sparse
     con.prefetch_sampling = prefetch   # (data-parallel default: on; then the rng states run one batch ahead)
     con.counts_min_records = 0
+    if pieces:
+        con.dp_pieces = pieces      # the flat buffers in `pieces` segments, each exchanged and updated on its own (Config._dp_exchange)
     con.init()
     con.set_model_and_session(getattr(pkg, model_name))
     assert con.sparse_rows == sparse
     if world > 1:
         con.init_distributed()
+        if pieces and not sparse:
+            assert con._pieces == pieces
     losses = [con.train_step() for _ in range(4)]
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, "w%d_r%d.npz" % (world, rank)), losses=np.array(losses),
@@ -58,14 +62,26 @@ def _run_worlds(tmp_path, worlds, *args):
 @pytest.mark.parametrize("model_name,opt,world", [("TransE", "SGD", 2), ("TransE", "Adam", 2), ("TransE", "Adam", 4), ("TransH", "SGD", 2),
                                                   ("TransD", "Adam", 4), ("TransR", "SGD", 2)])
 def test_ranks_equal_single_process(tmp_path, model_name, opt, world):
+    _ranks_equal_single_process(tmp_path, model_name, opt, world, 0)
+
+
+@pytest.mark.parametrize("model_name,opt,world", [("TransE", "Adam", 2), ("TransH", "SGD", 2), ("TransD", "Adam", 4)])
+def test_ranks_equal_single_process_in_two_pieces(tmp_path, model_name, opt, world):
+    """The same with the flat buffers cut into TWO pieces (what tables from 64 MB on get): each piece is reduce-scattered,
+    updated by its owners and all-gathered on its own, the loss riding in the LAST piece's spare tail slot."""
+    _ranks_equal_single_process(tmp_path, model_name, opt, world, 2)
+
+
+def _ranks_equal_single_process(tmp_path, model_name, opt, world, pieces):
     """Reduce-scatter of the gradient image, optimizer on the owned chunk, all-gather of the parameters: every replica
     holds the identical tables (one owner computes each element) and they equal the single-process run -- bit for bit
     for TransE (integer counts), to fp32 summation order for the fp32-accumulator models."""
-    res = _run_worlds(tmp_path, [1, world], model_name, opt)
+    res = _run_worlds(tmp_path, [1, world], model_name, opt, False, False, 10, pieces)
     one = res[1][0]
     for r in res[world]:
         assert np.array_equal(r["states"], one["states"])
         assert np.allclose(r["losses"], one["losses"], rtol=2e-5, atol=0)
+        assert np.array_equal(r["losses"], res[world][0]["losses"])      # the loss reaches every rank through the all-gather: same bits
     for k in one.files:
         if k in ("losses", "states"):
             continue
@@ -359,3 +375,64 @@ def test_two_rank_sharded_checkpoint_and_resume(tmp_path):
     assert int(second["step"]) == 20 and int(full["step"]) == 20
     for k in full.files:
         assert np.array_equal(second[k], full[k]), k
+
+
+def _oracle_worker(rank, world, port, out_dir, model_name, opt):
+    """Two ranks take ONE step; rank 0 also saves the tables the step started from and the global batch (host copies of both
+    ranks' slices are reassembled by the test from the oracle sampler, which the device sampler equals bit for bit)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import openkeonspark_amd as pkg
+    con = pkg.Config()
+    con.set_in_path(os.path.join(GOLDEN, "kg_small"))
+    con.set_work_threads(8); con.set_bern(1); con.set_dimension(48); con.set_nbatches(10)
+    con.set_ent_neg_rate(3); con.set_alpha(0.02); con.set_opt_method(opt)
+    con.prefetch_sampling = False
+    con.counts_min_records = 0
+    con.init()
+    con.set_model_and_session(getattr(pkg, model_name))
+    con.init_distributed()
+    before = con.get_parameters()
+    states = con.get_stream_states()
+    loss = con.train_step()
+    torch.cuda.synchronize()
+    after = con.get_parameters()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "oracle_case.npz"), loss=loss, states=states, batch=con.batch_size,
+                 **{"before_" + k: v for k, v in before.items()}, **{"after_" + k: v for k, v in after.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model_name,opt", [("TransE", "SGD"), ("TransE", "Adam"), ("TransH", "SGD")])
+def test_two_rank_step_against_the_oracle_full_batch_step(tmp_path, model_name, opt):
+    """A 2-rank step compared DIRECTLY with the oracle's step on the full global batch (not with the 1-rank engine): the ranks'
+    slices are the virtual sampler threads [0,4) and [4,8) of the reference's own partition (Base.cpp:85-92), each rank
+    differentiates its slice with the GLOBAL denominator, the images are summed -- so the result must be the single-process
+    reference step on the whole batch (TransE.py:26-51, distribute_training.py:95-101): loss to 2e-5, the update to 1e-5 of
+    its largest element (SGD) / 2e-4 (one Adam step)."""
+    import torch.multiprocessing as mp
+    from oracle import oracle
+    port = 29800 + os.getpid() % 1000
+    mp.start_processes(_oracle_worker, args=(2, port, str(tmp_path), model_name, opt), nprocs=2, join=True, start_method="spawn")
+    z = np.load(str(tmp_path / "oracle_case.npz"))
+    kg_dir = os.path.join(GOLDEN, "kg_small")
+    kg = oracle.KG(kg_dir, work_threads=8, bern=1)
+    kg.set_stream_states(z["states"])
+    B, n = int(z["batch"]), 3
+    bh, bt, br, _ = kg.sampling(B, n, 0)
+    before = {k[len("before_"):]: z[k] for k in z.files if k.startswith("before_")}
+    after = {k[len("after_"):]: z[k] for k in z.files if k.startswith("after_")}
+    orc = oracle.Model(model_name.lower(), kg.entTotal, kg.relTotal, 48, 48, margin=1.0, params=before)
+    loss_o = orc.sgd_step(bh, bt, br, B, n, 0.02) if opt == "SGD" else orc.adam_step(bh, bt, br, B, n, 0.02)
+    assert abs(float(z["loss"]) - loss_o) <= 2e-5 * abs(loss_o), (float(z["loss"]), loss_o)
+    tol = 1e-5 if opt == "SGD" else 2e-4
+    for k in before:
+        du_o = orc.params[k].astype(np.float64) - before[k]
+        du_g = after[k].astype(np.float64) - before[k]
+        quantum = np.abs(before[k]).max() * 2.0 ** -23
+        assert np.abs(du_g - du_o).max() <= tol * np.abs(du_o).max() + quantum, (k, np.abs(du_g - du_o).max(), np.abs(du_o).max())
