@@ -265,7 +265,16 @@ class Config(object):
         requested = getattr(self, "sparse_rows", None)   # None = automatic, True / False = the caller's wish
         sparse = requested
         if sparse is None:
-            sparse = table_bytes > int(getattr(self, "sparse_threshold_bytes", 8 << 30))
+            # Measured cross-over on one MI355X (tools/sparse_crossover.sh, profiles/r03_sparse_crossover.jsonl: dim 512,
+            # B = 131 072, n = 1, tables of 0.26 .. 8.2 GB): the dense step costs the batch's work plus a sweep of the whole
+            # table and count image, the sparse step the batch's work plus its sort -- they tie at 0.26 GB (0.68 vs 0.70 ms),
+            # sparse rows win by 18 % at 0.5 GB and 5.4x at 8 GB.  The tie sits where the table is ~0.3x the bytes of the rows
+            # a step touches (1.07 GB there); below 128 MB the dense path's image fits the caches and it is kept.
+            touched_bytes = self.batch_size * (3 + n_neg) * self.hidden_size * 4
+            threshold = getattr(self, "sparse_threshold_bytes", None)
+            if threshold is None:
+                threshold = max(128 << 20, int(0.3 * touched_bytes))
+            sparse = table_bytes > int(threshold)
         self.sparse_rows = bool(sparse) and self.use_counts and not self._adam
         if requested and not self.sparse_rows:
             raise KgeError("sparse_rows needs TransE (sign-count path: 1..63 negatives) with SGD")
