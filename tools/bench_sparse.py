@@ -23,7 +23,6 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--ent-exponent", type=float, default=0.8, help="Zipf exponent of entity popularity (0 = uniform)")
     ap.add_argument("--dense", action="store_true", help="dense count image instead of the sparse-row path")
-    ap.add_argument("--no-inplace", action="store_true", help="every touched row through records + the reducer (no in-place update in the emit kernel)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -49,7 +48,6 @@ def main():
     con.set_opt_method("SGD")
     con.set_nbatches(max(1, a.triples // a.batch))
     con.sparse_rows = not a.dense
-    con.sparse_inplace = not a.no_inplace
     t0 = time.time()
     con.init_from_arrays(a.entities, a.relations, h, t, r)
     t_index = time.time() - t0
