@@ -316,18 +316,6 @@ int kge_transe_apply_counts_range(const kge_model_desc *m, float *const d_p[2], 
 int kge_transe_set_bf16_shadow(const kge_model_desc *m, const float *d_ent, const float *d_rel, uint16_t *d_ent16, uint16_t *d_rel16,
                                void *stream);
 
-/* One sparse-row TransE + SGD step on ONE GPU in a single call: kge_transe_emit_records followed by
- * kge_transe_reduce_apply_records_sgd, except that a row which only ONE record slot of the batch addresses (found from the
- * batch ids alone, two bitmaps over the row space) is updated by the emit kernel itself and produces no record.  With the
- * uniform entity popularity of BASELINE config #5 that is ~96 % of the touched entity rows: they are gathered once instead
- * of twice and their 512-byte records are neither written nor read back.  Same per-row formula and the same integer counts
- * as the reducers: the tables get the same bits as from the two-call form.  d_rec / d_dst / d_rows / d_row_counts / d_n_rows
- * as for the two calls (d_dst pre-filled with -1); a batch that is not sampler-shaped must take the two-call form, whose
- * deferred-group count can be checked before anything is applied. */
-int kge_transe_sparse_step_sgd(const kge_model_desc *m, float *d_ent, float *d_rel, const int32_t *d_h, const int32_t *d_t,
-                               const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom, uint32_t *d_rec, int32_t *d_dst,
-                               int32_t *d_rows, int32_t *d_row_counts, int32_t *d_n_rows, float lr, float *d_loss, void *stream);
-
 /* ---- TransE sign-count path, stage level: for tables too large for a dense count image and for the
  * multi-GPU exchange, where the int8 records (8x smaller than fp32 gradient rows) are the wire format ----
  *   kge_transe_record_dwords : dwords per record for this embedding width

@@ -803,16 +803,6 @@ class Config(object):
             self._sparse_buf = buf
         st = self._stream()
         buf["dst"].fill_(-1)
-        if getattr(self, "sparse_fused", True) and D % 4 == 0 and getattr(self, "sparse_inplace", True) and not check_shape:
-            # one call: rows that a single record slot addresses are updated inside the emit kernel (gathered once, no record);
-            # the others go through records + the fused reduce-and-apply as below.  Same bits either way.
-            _lib.check(self.lib.kge_transe_sparse_step_sgd(
-                ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(),
-                dev_batch[0].data_ptr(), dev_batch[1].data_ptr(), dev_batch[2].data_ptr(), n_pos, n_neg,
-                dev_batch.shape[1] // (1 + n_neg), denom, buf["rec"].data_ptr(), buf["dst"].data_ptr(), buf["rows"].data_ptr(),
-                buf["row_counts"].data_ptr(), buf["n_rows"].data_ptr(), float(self.alpha), self._loss.data_ptr(), st), self.lib)
-            self.global_step += 1
-            return
         _lib.check(self.lib.kge_transe_emit_records(
             ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(),
             dev_batch[0].data_ptr(), dev_batch[1].data_ptr(), dev_batch[2].data_ptr(), n_pos, n_neg,

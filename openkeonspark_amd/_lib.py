@@ -94,7 +94,6 @@ def _declare(L):
     L.kge_transe_reduce_records.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, i64, vp, vp, vp, vp]
     L.kge_transe_apply_rows_sgd.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i64, f32, vp]
     L.kge_transe_reduce_apply_records_sgd.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, i64, vp, vp, vp, vp, vp, i64, f32, vp]
-    L.kge_transe_sparse_step_sgd.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, f32, vp, vp]
     L.kge_transe_apply_counts_range.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i64, i64, i32, f32, f32, f32, f32, vp]
     L.kge_transe_set_bf16_shadow.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp]
     # table-sharded sparse path (csrc/shard.hip)

@@ -20,7 +20,6 @@
 // Gradients are ADDED into dense per-table accumulators (the deduplicated IndexedSlices sum that
 // TF1 forms before the optimizer) with hardware fp32 atomics.
 #include "models_dev.hpp"
-#include "counts_dev.hpp"
 
 namespace kge {
 
@@ -245,9 +244,7 @@ __global__ __launch_bounds__(256) void transe_emit_kernel(FbArgs a) {
 //   * the integer gradient vectors are packed int16 pairs (v_pk_add_i16), bytes only when stored;
 //   * one global_load_dwordx4 per row chunk.  Record dword w = lane + L*q holds elements 4w..4w+3
 //     ("natural" layout, flagged to the reducers).
-// INPLACE (sparse rows on one GPU): a record whose destination row no other slot of the step addresses (FbArgs::dup_bits) is not
-// written -- the row's SGD update is applied here, from the row as it sits in the caches this team has just gathered it into.
-template <int L, int Q, int K, int WPE, bool INV_TAB, bool BF16 = false, bool INPLACE = false>
+template <int L, int Q, int K, int WPE, bool INV_TAB, bool BF16 = false>
 __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
     constexpr int TEAMS = 256 / L;
     __shared__ float red[TEAMS];
@@ -275,20 +272,6 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
             for (int q = 0; q < Q; q++)
                 x[q] = valid[q] ? *reinterpret_cast<const float4 *>(p + 4 * (lane + L * q)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    };
-    // in place: is `vrow` (row-space index: entity id, or E + relation id) addressed by this record alone?
-    auto sole = [&](int vrow) -> bool {
-        if constexpr (!INPLACE) return false;
-        else return ((a.dup_bits[vrow >> 5] >> (vrow & 31)) & 1u) == 0u;
-    };
-    auto apply_here = [&](const uint32_t (&w)[Q], bool is_rel, int row) {
-        int acc[4 * Q];
-#pragma unroll
-        for (int q = 0; q < Q; q++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[4 * q + j] = (int)(int8_t)(w[q] >> (8 * j));
-        float *prow = const_cast<float *>(is_rel ? a.rel : a.ent) + (long long)row * D;
-        apply_row_nat<L, 4 * Q>(acc, prow, D, lane, a.unit, a.inplace_lr);
     };
     float lsum = 0.f;
     for (long long b = (long long)blockIdx.x * TEAMS + team_in_block; b < a.n_pos; b += (long long)gridDim.x * TEAMS) {
@@ -450,12 +433,8 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
                             At_lo[q] += s_lo * kt; At_hi[q] += s_hi * kt;
                             Ar_lo[q] += s_lo * kr; Ar_hi[q] += s_hi * kr;
                         }
-                        const int vrow = code[u] == 2 ? rel_row0 + row[u] : row[u];
-                        if (sole(vrow)) apply_here(rec, code[u] == 2, row[u]);
-                        else {
-                            store_record<L, Q>(a, lane, m, rec);
-                            if (lane == kk + u) my_dst = vrow;
-                        }
+                        store_record<L, Q>(a, lane, m, rec);
+                        if (lane == kk + u) my_dst = code[u] == 2 ? rel_row0 + row[u] : row[u];
                     }
                 }
             }
@@ -472,17 +451,14 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
                 rt[q] = bytes_of(At_lo[q] - v_lo, At_hi[q] - v_hi);
                 rr[q] = bytes_of(Ar_lo[q] + v_lo, Ar_hi[q] + v_hi);
             }
-            const bool sh = sole(h), st = sole(t), sr = sole(rel_row0 + r);
-            if (sh) apply_here(rh, false, h); else store_record<L, Q>(a, lane, b, rh);
-            if (st) apply_here(rt, false, t); else store_record<L, Q>(a, lane, a.n_pos + b, rt);
-            if (sr) apply_here(rr, true, r); else store_record<L, Q>(a, lane, 2 * a.n_pos + b, rr);
-            if (lane == 0) {
-                a.dst[b] = sh ? -1 : (int32_t)h;
-                a.dst[a.n_pos + b] = st ? -1 : (int32_t)t;
-                a.dst[2 * a.n_pos + b] = sr ? -1 : (int32_t)(rel_row0 + r);
-            }
-        } else if (lane == 0) {
-            a.dst[b] = -1; a.dst[a.n_pos + b] = -1; a.dst[2 * a.n_pos + b] = -1;
+            store_record<L, Q>(a, lane, b, rh);
+            store_record<L, Q>(a, lane, a.n_pos + b, rt);
+            store_record<L, Q>(a, lane, 2 * a.n_pos + b, rr);
+        }
+        if (lane == 0) {
+            a.dst[b] = cnt > 0 ? (int32_t)h : -1;
+            a.dst[a.n_pos + b] = cnt > 0 ? (int32_t)t : -1;
+            a.dst[2 * a.n_pos + b] = cnt > 0 ? (int32_t)(rel_row0 + r) : -1;
         }
     }
     finish_loss<TEAMS>(a, red, lsum, lane, team_in_block);
@@ -556,10 +532,7 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
             if (!eng.ev_emit0[slot]) { (void)hipEventCreate(&eng.ev_emit0[slot]); (void)hipEventCreate(&eng.ev_emit1[slot]); }
             (void)hipEventRecord(eng.ev_emit0[slot], stream);
         }
-        if (a.dup_bits && !bf16) {
-            if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        } else if (bf16 && inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        if (bf16 && inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         else if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         if (timed) { (void)hipEventRecord(eng.ev_emit1[slot], stream); eng.emit_launches++; }
@@ -622,8 +595,7 @@ int transe_deferred_groups(int32_t *out) {
 
 int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *rel, float *resid_ent, float *resid_rel,
                        const int32_t *d_h, const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
-                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream, bool track_deferred,
-                       const uint32_t *dup_bits, float inplace_lr) {
+                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream, bool track_deferred) {
     // track_deferred = false: the caller guarantees sampler-shaped negatives (a device-sampled batch): no
     // deferral list, no counter reset, no fp32 pass
     Engine &e = engine();
@@ -663,7 +635,6 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
     a.loss_partials = e.dev.loss_partials;
     a.negative_rel = m.negative_rel;
     a.rec = rec; a.dst = dst; a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total; a.krel = 1;
-    a.dup_bits = (m.ent_dim % 4 == 0) ? dup_bits : nullptr; a.inplace_lr = inplace_lr;
     while (a.krel * 2 <= krel) a.krel *= 2;      // a power of two: the kernels take b & (krel - 1)
     const int D = a.D;
     if (D % 4 == 0 && D <= 64) launch_emit<16, 4>(a, d_loss, stream);

@@ -23,12 +23,6 @@ struct FbArgs {
     // TransE sign-count path (transe_counts.hip): int8 gradient records + destination rows
     uint32_t *rec;
     int32_t *dst;
-    // sparse rows, one GPU (kge_transe_sparse_step_sgd): bit (row & 31) of dup_bits[row >> 5] is set for every row of the [E + R]
-    // row space that MORE THAN ONE record slot of this step addresses.  A row with its bit clear is read and written by one
-    // group only, so the emit kernel (INPLACE instantiation) applies its SGD update on the spot (counts_dev.hpp apply_row_nat,
-    // the reducers' own formula) instead of writing a record -- the row is not gathered a second time by the reducer.
-    const uint32_t *dup_bits;
-    float inplace_lr;
     int ent_total, rel_total, krel;
     // indirection for the deferred groups of the sign-count path: when group_list != nullptr the
     // kernel walks group_list[0 .. *group_count) instead of 0 .. n_pos

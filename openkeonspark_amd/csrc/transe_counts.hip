@@ -25,15 +25,13 @@
 #include "engine.hpp"
 #include "team.hpp"
 #include "sampler_dev.hpp"
-#include "counts_dev.hpp"
 
 namespace kge {
 
 void transe_team_shape(int D, int &L, int &C);
 int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *rel, float *resid_ent, float *resid_rel,
                        const int32_t *d_h, const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
-                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream, bool track_deferred,
-                       const uint32_t *dup_bits = nullptr, float inplace_lr = 0.f);
+                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream, bool track_deferred);
 
 int transe_deferred_groups(int32_t *out);
 
@@ -183,6 +181,59 @@ __device__ __forceinline__ uint16_t bf16_rne(float f) {
     if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
+}
+
+// d/dx of the normalised row applied to the integer sign sum: unit * (1/|x|) * (S - x^ <x^,S>), with every
+// operation individually rounded so that all apply kernels agree bit for bit given the same reduction order
+__device__ __forceinline__ float count_grad(float unit, float inv, float s, float d, float xn) {
+    return __fmul_rn(__fmul_rn(unit, inv), __fsub_rn(s, __fmul_rn(d, xn)));
+}
+
+// Sparse-row SGD on ONE row from its summed integer counts held in the NATURAL layout of the vectorised kernels
+// (accumulator c of lane l = element 4*(l + L*(c/4)) + c%4; D % 4 == 0): the single arithmetic used by the fused
+// segmented-sum-and-apply kernel and by the row-list apply kernel, so a row gets the same bits whichever of them
+// handles it (which one does depends on where chunk boundaries fall, i.e. on the number of ranks).
+template <int L, int C>
+__device__ __forceinline__ void apply_row_nat(const int (&acc)[C], float *__restrict__ p, int D, int lane, float unit, float lr) {
+    constexpr int Q = (C + 3) / 4;
+    float x[4 * Q], sv[4 * Q];
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int e0 = 4 * (lane + L * q);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e0 < D) v = *reinterpret_cast<const float4 *>(p + e0);
+        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            sv[4 * q + j] = (4 * q + j < C) ? (float)acc[(4 * q + j < C) ? 4 * q + j : 0] : 0.f;
+            ss += x[4 * q + j] * x[4 * q + j];
+        }
+    }
+    ss = team_sum<L>(ss);
+    const bool uc = ss >= 1e-12f;
+    const float inv = 1.0f / sqrtf(uc ? ss : 1e-12f);
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4 * Q; c++) d += (x[c] * inv) * sv[c];
+    d = team_sum<L>(d);
+    if (!uc) d = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int e0 = 4 * (lane + L * q);
+        if (e0 < D) {
+            float o[4];
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int c = 4 * q + j;
+                const float g = __fadd_rn(count_grad(unit, inv, sv[c], d, x[c] * inv), 0.f);
+                o[j] = g != 0.f ? __fsub_rn(x[c], __fmul_rn(lr, g)) : x[c];
+                any = any || g != 0.f;
+            }
+            if (any) *reinterpret_cast<float4 *>(p + e0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
 }
 
 // fused segmented sum + apply (sparse rows, SGD): rows whose records all lie inside one chunk are updated straight from
@@ -920,36 +971,6 @@ int pair_records_reduce(int model, int64_t M, int64_t n_int8, int D, int rd, int
 
 namespace {
 
-// Which rows of the [E + R] row space does more than one record slot of this batch address?  One thread per slot (the positive's
-// h / t / r, then the corrupted slot of every negative -- the destinations the emit kernel will write, Base.cpp:109-139 layout):
-// the first visitor sets the row's bit in `seen`, any later one its bit in `dup`.  Two bitmaps of (E + R) / 8 bytes each,
-// cleared per step by a memset (12.5 MB at 50 M rows: microseconds); the atomics are 4-byte ORs spread over the whole bitmap.
-__global__ void mark_rows_kernel(const int32_t *__restrict__ bh, const int32_t *__restrict__ bt, const int32_t *__restrict__ br,
-                                 long long n_pos, long long n_neg, long long stride, int negative_rel, int E,
-                                 uint32_t *__restrict__ seen, uint32_t *__restrict__ dup) {
-    const long long M = n_pos * (3 + n_neg);
-    for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long long)gridDim.x * blockDim.x) {
-        const long long slot = m / n_pos, b = m - slot * n_pos;
-        const int h = bh[b], t = bt[b], r = br[b];
-        int row;
-        if (slot == 0) row = h;
-        else if (slot == 1) row = t;
-        else if (slot == 2) row = E + r;
-        else {
-            const long long j = b + (slot - 2) * stride;
-            const int nh = bh[j], nt = bt[j], nr = br[j];
-            const NegClass nc = classify_negative<KGE_TRANSE>(h, t, r, nh, nt, nr, negative_rel);
-            row = !nc.same_h ? nh : (!nc.same_t ? nt : E + nr);
-        }
-        const uint32_t bit = 1u << (row & 31);
-        const uint32_t old = atomicOr(&seen[row >> 5], bit);
-        if (old & bit) atomicOr(&dup[row >> 5], bit);
-    }
-}
-
-uint32_t *g_row_bits = nullptr;      // [2][words]: seen, dup
-int64_t g_row_bits_words = 0;
-
 // SGD on listed rows from the compact image, natural layout (D % 4 == 0); bflag != nullptr: only flagged rows
 template <int L, int C>
 __global__ __launch_bounds__(256) void apply_rows_nat_kernel(FuseArgs fz, const int32_t *__restrict__ row_list, const int32_t *__restrict__ S,
@@ -1302,42 +1323,9 @@ int kge_transe_reduce_apply_records_sgd(const kge_model_desc *m, const uint32_t 
                                         void *stream_) {
     if (!m || !d_ent || !d_rel || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_transe_reduce_apply_records_sgd: bad arguments");
     tables_written();
-    FuseArgs fz = FuseArgs();
+    FuseArgs fz;
     fz.ent = d_ent; fz.rel = d_rel; fz.E = m->ent_total; fz.unit = 1.0f / (float)denom; fz.lr = lr;
     return reduce_records_impl(m, d_rec, d_dst, n_records, d_rows, d_row_counts, d_n_rows, &fz, (hipStream_t)stream_);
-}
-
-int kge_transe_sparse_step_sgd(const kge_model_desc *m, float *d_ent, float *d_rel, const int32_t *d_h, const int32_t *d_t,
-                               const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom, uint32_t *d_rec, int32_t *d_dst,
-                               int32_t *d_rows, int32_t *d_row_counts, int32_t *d_n_rows, float lr, float *d_loss, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_sparse_step_sgd: no usable HIP device");
-    if (!m || !d_ent || !d_rel || !d_h || !d_t || !d_r || !d_rec || !d_dst || !d_rows || !d_row_counts || !d_n_rows || !d_loss ||
-        !kge_transe_counts_supported(m, n_neg) || m->ent_dim % 4 || n_pos < 0 || stride < n_pos || denom <= 0)
-        return fail(KGE_ERR_BAD_ARG, "kge_transe_sparse_step_sgd: TransE, width a multiple of 4, 1..63 negatives, consistent sizes");
-    if (n_pos == 0) return hip_check(hipMemsetAsync(d_loss, 0, sizeof(float), stream), "zero loss");
-    const int64_t M = n_pos * (3 + n_neg);
-    if (M >= (int64_t(1) << 31)) return fail(KGE_ERR_UNSUPPORTED, "batch too large for the sign-count path");
-    const int64_t rows = m->ent_total + m->rel_total, words = (rows + 31) / 32;
-    int rc;
-    if (words > g_row_bits_words) {
-        if ((rc = regrow(g_row_bits, (size_t)(2 * words), "row bitmaps"))) return rc;
-        g_row_bits_words = words;
-    }
-    if ((rc = hip_check(hipMemsetAsync(g_row_bits, 0, sizeof(uint32_t) * 2 * (size_t)words, stream), "zero row bitmaps"))) return rc;
-    uint32_t *seen = g_row_bits, *dup = g_row_bits + words;
-    int blocks = (int)((M + 255) / 256);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(mark_rows_kernel, dim3(blocks), dim3(256), 0, stream, d_h, d_t, d_r, (long long)n_pos, (long long)n_neg,
-                       (long long)stride, (int)m->negative_rel, (int)m->ent_total, seen, dup);
-    tables_written();
-    // records only for the rows that several slots address; every other active slot updates its row in the emit kernel
-    rc = launch_transe_emit(*m, d_ent, d_rel, nullptr, nullptr, d_h, d_t, d_r, n_pos, n_neg, stride, denom, d_rec, d_dst, 1, d_loss,
-                            stream, true, dup, lr);
-    if (rc) return rc;
-    FuseArgs fz = FuseArgs();
-    fz.ent = d_ent; fz.rel = d_rel; fz.E = m->ent_total; fz.unit = 1.0f / (float)denom; fz.lr = lr;
-    return reduce_records_impl(m, d_rec, d_dst, M, d_rows, d_row_counts, d_n_rows, &fz, stream);
 }
 
 int kge_transe_apply_rows_sgd(const kge_model_desc *m, float *d_ent, float *d_rel, const int32_t *d_rows, const int32_t *d_row_counts,
