@@ -695,9 +695,11 @@ class Config(object):
             ahead = batch_h is None and self.prefetch_sampling
             if ahead:
                 self._attach_next_batch()              # rides in the scatter launch enqueued by forward_counts
-            self.forward_counts(dev, n_pos, stride, denom, sampler_shaped=batch_h is None)
-            if ahead:
-                self._flush_next_batch()               # (launched on its own if the step's path had no scatter kernel)
+            try:
+                self.forward_counts(dev, n_pos, stride, denom, sampler_shaped=batch_h is None)
+            finally:
+                if ahead:                              # launched on its own if the step's path had no scatter kernel -- and
+                    self._flush_next_batch()           # also when the forward call failed: an armed sampler never outlives its buffers
             if self.world_size > 1:
                 # int32 SUM is exact: rank g receives the summed counts of ITS rows, updates them, and the updated rows go round
                 self._dp_exchange(self._counts, self._counts_own, lambda k: self.apply_counts(denom, own=True, piece=k), counts=True)

@@ -108,6 +108,8 @@ static void adopt_index(KgIndex &&ix) {
 // both produce the same arrays bit for bit
 static std::string build_and_adopt(int64_t E, int64_t R, int64_t nb, int64_t n, const int64_t *h, const int64_t *t, const int64_t *r) {
     Engine &e = engine();
+    // an armed sampler (kge_sampling_attach) points into the index arrays that are about to be replaced: run it first
+    if (device_ok()) { (void)flush_attached_sampler(nullptr); (void)hipDeviceSynchronize(); }
     if (e.index_device_min >= 0 && n >= e.index_device_min && device_ok() && device_index_build_supported(E, R, n)) {
         KgIndex ix;
         std::string err = build_index_device(ix, e.dev, E, R, nb, n, h, t, r);

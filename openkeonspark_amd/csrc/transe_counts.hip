@@ -439,7 +439,8 @@ __global__ __launch_bounds__(256) void bkt_scatter_kernel(const int32_t *__restr
 static void launch_bkt_scatter(int n_tiles, int M, int rpb, int32_t *totals, int32_t *cursor, int2 *pairs, hipStream_t stream) {
     SamplerArgs ride = {};
     unsigned n_ride = 0;
-    if (take_attached_sampler(ride, n_ride) && upload_jump_table() != KGE_OK) n_ride = 0;   // (the upload cannot fail once the sampler's own has succeeded)
+    // this translation unit's copy of the jump table first: an armed sampler is only taken along once it can run here
+    if (upload_jump_table() == KGE_OK && !take_attached_sampler(ride, n_ride)) n_ride = 0;
     hipLaunchKernelGGL(bkt_scatter_kernel, dim3((unsigned)n_tiles + n_ride), dim3(256), 0, stream, g_c.dst, M, rpb, totals, g_c.bucket_start,
                        cursor, pairs, ride, n_tiles, (int)n_ride);
 }
