@@ -608,9 +608,16 @@ __global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // t
         }
         __syncthreads();
         if (k0 + KC2 < K) KGE_LOAD_CHUNK(k0 + KC2)   // in flight during the MFMA loop
-        // one block variant only (two would each get their own accumulator registers): a wave with any live row multiplies
-        // both of its sub-tiles, the padding rows being zero
-        if (n_live > 0) gemm2_mfma_block<MODE, NT, RT2>(As, Bs, acc, wave, lane);
+        // a wave with rows in both of its sub-tiles multiplies both; a tile of at most 64 rows (the tail of a relation's bucket:
+        // ~1 tile in 8 at B = 34 014, nearly every tile at the reference's own batch) only has first sub-tiles, and the
+        // one-sub-tile instantiation on the SAME accumulator array does half the matrix work
+        // (7-tile instantiations only: with 13 column tiles a second block variant pushes the kernel past 256 VGPRs into scratch)
+        if constexpr (NT <= 7) {
+            if (rows > RM2) gemm2_mfma_block<MODE, NT, RT2>(As, Bs, acc, wave, lane);
+            else if (n_live > 0) gemm2_mfma_block<MODE, NT, 1>(As, Bs, acc, wave, lane);
+        } else {
+            if (n_live > 0) gemm2_mfma_block<MODE, NT, RT2>(As, Bs, acc, wave, lane);
+        }
     }
 #undef KGE_LOAD_CHUNK
     if (MODE == GEMM_DGRAD && a.rec_out && blockIdx.y == 0 && tid < rows) a.rec_dst[row0 + tid] = s_ent[tid];
