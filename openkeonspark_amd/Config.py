@@ -340,7 +340,8 @@ class Config(object):
             self.batch_size * (3 + n_neg) >= int(getattr(self, "counts_min_records", 1 << 16)) * self.world_size
         pair_path = getattr(self, "_desc", None) is not None and \
             bool(self.lib.kge_pair_path_active(ctypes.byref(self._desc), max(self._n_local, 1) if hasattr(self, "_n_local") else self.batch_size, n_neg))
-        return bool(self.world_size > 1 or counts_path or pair_path)
+        transr = getattr(self, "trainModel", None) is not None and self.trainModel.model_id == _lib.TRANSR
+        return bool(self.world_size > 1 or counts_path or pair_path or transr)
 
     def _setup_partition(self):
         from .parallel import thread_range
@@ -708,8 +709,17 @@ class Config(object):
             else:
                 self.apply_counts(denom)
         else:
-            self.forward_backward(dev, n_pos, stride, denom, sampler_shaped=batch_h is None)
-            if batch_h is None and self.prefetch_sampling:
+            # TransR on one GPU: the next batch's sampler rides in the relation-scatter launch of the step (a dozen to a hundred
+            # workgroups on 256 CUs), as it rides in the bucket scatter of the TransE path; other models keep the side stream
+            ride = batch_h is None and self.prefetch_sampling and self.world_size == 1 and self.trainModel.model_id == _lib.TRANSR
+            if ride:
+                self._attach_next_batch()
+            try:
+                self.forward_backward(dev, n_pos, stride, denom, sampler_shaped=batch_h is None)
+            finally:
+                if ride:
+                    self._flush_next_batch()
+            if batch_h is None and self.prefetch_sampling and not ride:
                 self._prefetch_next_batch(behind_emit=bool(self.lib.kge_pair_path_active(ctypes.byref(self._desc), n_pos, n_neg)))
             if self.world_size > 1:
                 self._dp_exchange(self._flat_g, self._grads_own, lambda k: self.apply_gradients(own=True, piece=k), counts=False)

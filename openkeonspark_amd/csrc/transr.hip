@@ -23,6 +23,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "engine.hpp"
+#include "sampler_dev.hpp"
 
 namespace kge {
 
@@ -178,7 +179,14 @@ __global__ __launch_bounds__(256) void rel_scatter_kernel(const int32_t *__restr
                                                           int32_t *__restrict__ hist, int32_t *__restrict__ cursor,
                                                           int32_t *__restrict__ sorted_vals, int32_t *__restrict__ bucket_start,
                                                           int32_t *__restrict__ tile_rel, int32_t *__restrict__ tile_row0,
-                                                          int32_t *__restrict__ n_tiles, int tile_shift) {
+                                                          int32_t *__restrict__ n_tiles, int tile_shift, SamplerArgs ride, int n_own, int n_ride) {
+    // workgroups beyond the scatter's own carry the NEXT batch's sampler (kge_sampling_attach): this launch has a dozen to a
+    // hundred workgroups and leaves the chip idle, the sampler is independent of everything in the step
+    if ((int)blockIdx.x >= n_own) {
+        __shared__ float bern_lds[kBernLds];
+        sample_block(ride, (long long)blockIdx.x - n_own, n_ride, bern_lds);
+        return;
+    }
     const int bins = (R + 1) * kRelSub;
     __shared__ int start[kRelBins + 1];      // exclusive scan of the histogram
     __shared__ int cnt[kRelBins];            // this tile's histogram, then its base per bin
@@ -842,8 +850,12 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
         g_w.rel_parity ^= 1;
         const unsigned tiles = (unsigned)((slots + kRelTile - 1) / kRelTile);
         hipLaunchKernelGGL(rel_count_kernel, dim3(tiles), dim3(256), 0, stream, g_w.keys, (int)slots, ((int)R + 1) * kRelSub, pair, other);
-        hipLaunchKernelGGL(rel_scatter_kernel, dim3(tiles), dim3(256), 0, stream, g_w.keys, g_w.vals, (int)slots, (int)R, pair,
-                           pair + kRelBins, g_w.vals2, g_w.bucket_start, g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, v2 ? 7 : 5);
+        SamplerArgs ride = {};
+        unsigned n_ride = 0;
+        if (upload_jump_table() == KGE_OK && !take_attached_sampler(ride, n_ride)) n_ride = 0;
+        hipLaunchKernelGGL(rel_scatter_kernel, dim3(tiles + n_ride), dim3(256), 0, stream, g_w.keys, g_w.vals, (int)slots, (int)R, pair,
+                           pair + kRelBins, g_w.vals2, g_w.bucket_start, g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, v2 ? 7 : 5, ride,
+                           (int)tiles, (int)n_ride);
     } else {
         size_t tmp = g_w.sort_tmp_bytes;
         rc = hip_check(rocprim::radix_sort_pairs(g_w.sort_tmp, tmp, g_w.keys, g_w.keys2, g_w.vals, g_w.vals2, (size_t)slots, 0,

@@ -495,6 +495,30 @@ def test_prefetched_sampling_is_bit_identical(fb_dir, D, force_sort):
     assert runs[0][2].tolist() == runs[1][2].tolist()      # rewound by the one batch drawn ahead: the same rng states
 
 
+def test_transr_sampler_riding_in_the_relation_scatter_draws_the_same_batches(fb_dir):
+    """TransR on one GPU: with prefetch_sampling (the default there) the next batch's sampler is armed before the step and rides in
+    its relation-scatter launch.  Same batches in the same order: the rng states (rewound by the batch drawn ahead) and the
+    losses equal those of sampling at the start of every step; the tables agree to fp32-atomic summation order."""
+    from openkeonspark_amd.Config import Config
+    from openkeonspark_amd.TransR import TransR
+    runs = []
+    for prefetch in (False, True):
+        con = Config()
+        con.prefetch_sampling = prefetch
+        con.set_in_path(fb_dir); con.set_work_threads(8); con.set_bern(0); con.set_dimension(48); con.set_nbatches(50)
+        con.set_ent_neg_rate(1); con.set_alpha(0.01); con.set_opt_method("SGD")
+        con.init()
+        seeds = np.array(oracle.libc_rand_sequence(8), dtype=np.uint64)
+        con.lib.kge_set_stream_states(seeds.ctypes.data, 8)
+        con.set_model_and_session(TransR)
+        losses = [con.train_step() for _ in range(5)]
+        runs.append((losses, con.get_parameters(), con.get_stream_states(before_prefetch=True)))
+    assert np.allclose(runs[0][0], runs[1][0], rtol=2e-6, atol=0)
+    assert runs[0][2].tolist() == runs[1][2].tolist()
+    for k in runs[0][1]:
+        assert np.abs(runs[0][1][k] - runs[1][1][k]).max() <= 1e-5 * np.abs(runs[0][1][k]).max(), k
+
+
 @pytest.mark.parametrize("D,opt", [(200, "Adam"), (100, "SGD"), (64, "Adam"), (200, "SGD")])
 def test_inverse_norm_table_carried_across_steps_is_bit_identical(fb_dir, D, opt):
     """The vectorised emit kernel reads 1/|row| from a per-row table.  The full-table apply kernel refreshes the entry of every
