@@ -266,6 +266,8 @@ def main():
     con.init()
     con.set_model_and_session(TransE)
     if use_dist:
+        if os.environ.get("KGE_BENCH_FORCE_DP") == "1":     # one-GPU rehearsal: a one-rank group takes the whole data-parallel exchange
+            con.force_data_parallel = True
         con.init_distributed()
     sys.stdout.flush()
     con.lib.kge_clear_error()

@@ -343,6 +343,13 @@ class Config(object):
         transr = getattr(self, "trainModel", None) is not None and self.trainModel.model_id == _lib.TRANSR
         return bool(self.world_size > 1 or counts_path or pair_path or transr)
 
+    @property
+    def _dp(self):
+        """Does a step go through the data-parallel exchange?  More than one rank -- or `force_data_parallel` on a one-rank
+        process group: the rehearsal of the RCCL path (collectives on device memory, asynchronous work handles, the in-place
+        all-gather) on a box with a single GPU; results equal the plain single-process step bit for bit."""
+        return self.world_size > 1 or bool(getattr(self, "force_data_parallel", False))
+
     def _setup_partition(self):
         from .parallel import thread_range
         lo, hi = thread_range(self.rank, self.world_size, self.workThreads)
@@ -350,7 +357,7 @@ class Config(object):
         first = ctypes.c_int64(0)
         self._n_local = self.lib.kge_slice_positions(self.batch_size, lo, hi, ctypes.byref(first))
         self._first_pos = first.value
-        if self.world_size > 1 and self.trainModel is not None and getattr(self, "_dist_ready", 0) != self.world_size:
+        if self._dp and self.trainModel is not None and getattr(self, "_dist_ready", 0) != self.world_size:
             if self.sparse_rows:
                 self._setup_shards()
             else:
@@ -654,7 +661,7 @@ class Config(object):
     def sync_optimizer_state(self):
         """Data-parallel Adam keeps m and v current on their owner only; gather them before they are read as whole tables
         (checkpoints)."""
-        if self.world_size > 1 and self._adam and not self.sparse_rows and not getattr(self, "_opt_state_synced", True):
+        if self._dp and self._adam and not self.sparse_rows and not getattr(self, "_opt_state_synced", True):
             from .parallel import all_gather_chunks
             for (slo, shi), (lo, hi) in zip(self._piece_seg, self._piece_own):
                 all_gather_chunks(self._flat_m[slo:shi], self._flat_m[lo:hi], self._pg)
@@ -686,7 +693,7 @@ class Config(object):
         # (same decision on every rank: it depends on the global batch only)
         big = (self.batch_size if batch_h is None else n_pos) * (3 + n_neg) >= self.counts_min_records * self.world_size
         if self.sparse_rows:
-            if self.world_size > 1:
+            if self._dp:
                 self._sharded_step(dev, n_pos, stride, denom)
             else:
                 self._sparse_step(dev, n_pos, stride, denom, check_shape=batch_h is not None)
@@ -701,7 +708,7 @@ class Config(object):
             finally:
                 if ahead:                              # launched on its own if the step's path had no scatter kernel -- and
                     self._flush_next_batch()           # also when the forward call failed: an armed sampler never outlives its buffers
-            if self.world_size > 1:
+            if self._dp:
                 # int32 SUM is exact: rank g receives the summed counts of ITS rows, updates them, and the updated rows go round
                 self._dp_exchange(self._counts, self._counts_own, lambda k: self.apply_counts(denom, own=True, piece=k), counts=True)
                 self.tables_changed()
@@ -711,7 +718,7 @@ class Config(object):
         else:
             # TransR on one GPU: the next batch's sampler rides in the relation-scatter launch of the step (a dozen to a hundred
             # workgroups on 256 CUs), as it rides in the bucket scatter of the TransE path; other models keep the side stream
-            ride = batch_h is None and self.prefetch_sampling and self.world_size == 1 and self.trainModel.model_id == _lib.TRANSR
+            ride = batch_h is None and self.prefetch_sampling and not self._dp and self.trainModel.model_id == _lib.TRANSR
             if ride:
                 self._attach_next_batch()
             try:
@@ -721,7 +728,7 @@ class Config(object):
                     self._flush_next_batch()
             if batch_h is None and self.prefetch_sampling and not ride:
                 self._prefetch_next_batch(behind_emit=bool(self.lib.kge_pair_path_active(ctypes.byref(self._desc), n_pos, n_neg)))
-            if self.world_size > 1:
+            if self._dp:
                 self._dp_exchange(self._flat_g, self._grads_own, lambda k: self.apply_gradients(own=True, piece=k), counts=False)
             else:
                 self.apply_gradients()
@@ -731,7 +738,7 @@ class Config(object):
     def persistent_supported(self):
         """Can train_steps() run its steps inside one persistent launch (csrc/persist.hip)?  Single process, the dense
         fp32-accumulator path of TransE / TransH / TransD at a launch-latency-bound step size."""
-        if self.world_size != 1 or self.sparse_rows or self.hidden_size > 256:
+        if self._dp or self.sparse_rows or self.hidden_size > 256:
             return False
         if self.trainModel.model_id not in (_lib.TRANSE, _lib.TRANSH, _lib.TRANSD):
             return False
@@ -1177,7 +1184,7 @@ class Config(object):
         return self.trainModel.parameter_lists
 
     def _sharded(self, var_name):
-        return self.world_size > 1 and getattr(self, "sparse_rows", False) and var_name == "ent_embeddings" and hasattr(self, "_shard")
+        return self._dp and getattr(self, "sparse_rows", False) and var_name == "ent_embeddings" and hasattr(self, "_shard")
 
     def get_parameters_by_name(self, var_name):
         if var_name in self.trainModel.parameter_lists:

@@ -122,7 +122,7 @@ def get_last_step(output_path):
 
 
 def _sharded(con):
-    return con.world_size > 1 and getattr(con, "sparse_rows", False) and hasattr(con, "_shard")
+    return con._dp and getattr(con, "sparse_rows", False) and hasattr(con, "_shard")
 
 
 def checkpoint_arrays(con):

@@ -12,7 +12,7 @@ from conftest import GOLDEN, ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=False, nbatches=10, pieces=0):
+def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=False, nbatches=10, pieces=0, rccl_one_rank=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -20,6 +20,9 @@ def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=
     os.environ["MASTER_PORT"] = str(port)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif rccl_one_rank:     # a ONE-rank RCCL group: the collectives of the data-parallel step on device memory, as the 8-GPU run issues them
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
     import openkeonspark_amd as pkg
     if sparse:   # the sharded step emits against a per-step row cache: norms from the gathered rows in both runs
         pkg._lib.lib().kge_set_option(b"inv_table_max_bytes", 0)
@@ -38,15 +41,19 @@ def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=
     con.init()
     con.set_model_and_session(getattr(pkg, model_name))
     assert con.sparse_rows == sparse
-    if world > 1:
+    if rccl_one_rank:
+        con.force_data_parallel = True
+    if world > 1 or rccl_one_rank:
         con.init_distributed()
         if pieces and not sparse:
             assert con._pieces == pieces
+    if rccl_one_rank:
+        assert con._dp and dist.get_backend() == "nccl" and (sparse or hasattr(con, "_flat_p"))
     losses = [con.train_step() for _ in range(4)]
     torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, "w%d_r%d.npz" % (world, rank)), losses=np.array(losses),
+    np.savez(os.path.join(out_dir, "w%d_r%d%s.npz" % (world, rank, "_rccl" if rccl_one_rank else "")), losses=np.array(losses),
              states=con.get_stream_states(), **con.get_parameters())
-    if world > 1:
+    if world > 1 or rccl_one_rank:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -153,6 +160,9 @@ def _lp_worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif rccl_one_rank:     # a ONE-rank RCCL group: the collectives of the data-parallel step on device memory, as the 8-GPU run issues them
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
     import openkeonspark_amd as pkg
     con = pkg.Config()
     con.set_in_path(os.path.join(GOLDEN, "kg_small"))
@@ -315,6 +325,9 @@ def _config5_worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif rccl_one_rank:     # a ONE-rank RCCL group: the collectives of the data-parallel step on device memory, as the 8-GPU run issues them
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
     import openkeonspark_amd as pkg
     pkg._lib.lib().kge_set_option(b"inv_table_max_bytes", 0)
     rng = np.random.default_rng(5)
@@ -447,3 +460,29 @@ def test_two_rank_step_against_the_oracle_full_batch_step(tmp_path, model_name, 
             zero = np.zeros_like(before[k])
             rep = adam_update_explained(before[k], zero, zero, g_o[k], du_g, du_o, float(oracle.adam_lr_t(0.02, 0.9, 0.999, 1)))
             assert rep["unexplained"].size == 0, (k, rep["unexplained"][:8], rep["worst_steps"])
+
+
+@pytest.mark.parametrize("model_name,opt,sparse,pieces", [("TransE", "Adam", False, 2), ("TransE", "SGD", False, 0), ("TransH", "SGD", False, 2),
+                                                          ("TransR", "SGD", False, 0), ("TransE", "SGD", True, 0)])
+def test_one_rank_rccl_group_runs_the_data_parallel_step(tmp_path, model_name, opt, sparse, pieces):
+    """The box has one GPU, so RCCL cannot run with two ranks here -- but it can run with ONE: `force_data_parallel` sends the
+    step of a one-rank "nccl" process group through the whole exchange (asynchronous reduce-scatter of the count / gradient image
+    on device memory, optimizer on the owned share, in-place all-gather, the loss riding in the buffers; for the sharded table
+    the all-to-all exchanges).  Every collective is then a copy, so tables, losses and rng states must equal the plain
+    single-process run: bit for bit for TransE (integer counts), to the order of the fp32 atomics for the other models (two
+    plain runs of those differ by as much).  What this pins that the
+    `gloo` tests cannot: stream ordering between the engine's kernels and RCCL's own stream, int32 / fp32 reduce-scatter and the
+    in-place all-gather on device buffers."""
+    import torch.multiprocessing as mp
+    port = 29700 + os.getpid() % 1000
+    prefetch = not sparse
+    mp.start_processes(_worker, args=(1, port, str(tmp_path), model_name, opt, sparse, prefetch, 10, 0), nprocs=1, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(1, port + 1, str(tmp_path), model_name, opt, sparse, prefetch, 10, pieces, True), nprocs=1, join=True,
+                       start_method="spawn")
+    plain, rccl = np.load(str(tmp_path / "w1_r0.npz")), np.load(str(tmp_path / "w1_r0_rccl.npz"))
+    assert sorted(plain.files) == sorted(rccl.files)
+    for k in plain.files:
+        if model_name == "TransE" or k == "states":
+            np.testing.assert_array_equal(plain[k], rccl[k], err_msg=k)
+        else:
+            np.testing.assert_allclose(rccl[k], plain[k], rtol=1e-5, atol=1e-7, err_msg=k)
