@@ -339,6 +339,15 @@ int kge_transe_reduce_records(const kge_model_desc *m, const uint32_t *d_rec, in
                               int32_t *d_row_counts, int32_t *d_n_rows, void *stream);
 int kge_transe_apply_rows_sgd(const kge_model_desc *m, float *d_ent, float *d_rel, const int32_t *d_rows, const int32_t *d_row_counts,
                               const int32_t *d_n_rows, INT max_rows, INT denom, float lr, void *stream);
+/* NON-PARITY, opt-in ("LazyAdam"): Adam on the touched rows only -- m = b1 m + (1-b1) g, v = b2 v + (1-b2) g^2,
+ * p -= lr_t m / (sqrt(v) + eps) for the rows listed in d_rows (every element of a listed row, zero gradients included), all
+ * other rows and their moments left alone: tf.contrib.opt.LazyAdamOptimizer's rule, NOT what the reference trains with (TF1's
+ * AdamOptimizer moves every row of the table every step, distribute_training.py:96 -- kge_transe_apply_counts / kge_adam_dense
+ * are the parity path).  For tables whose dense sweep (32 bytes per element per step) would dominate the step.  lr_t =
+ * lr sqrt(1 - b2^t) / (1 - b1^t) with the global step t, computed by the caller. */
+int kge_transe_apply_rows_adam_lazy(const kge_model_desc *m, float *d_ent, float *d_rel, float *d_m_ent, float *d_m_rel, float *d_v_ent,
+                                    float *d_v_rel, const int32_t *d_rows, const int32_t *d_row_counts, const int32_t *d_n_rows,
+                                    INT max_rows, INT denom, float lr_t, float beta1, float beta2, float eps, void *stream);
 /* reduce + apply in one pass (embedding width a multiple of 4): rows whose records all fall inside one 64-record chunk
  * of the sorted list are updated straight from the registers that hold their sum; only chunk-boundary rows go through
  * d_row_counts and a second, small pass.  Same bits as kge_transe_reduce_records + kge_transe_apply_rows_sgd.

@@ -253,6 +253,11 @@ class Config(object):
         self._desc = m.descriptor()
         self._tables = [m.parameter_lists[n] for n in m.table_names]
         self._adam = self.opt_method in ("Adam", "adam")  # distribute_training.py:95
+        # opt-in, NON-PARITY: Adam on the touched rows only (tf.contrib.opt.LazyAdamOptimizer's rule) for tables whose dense
+        # TF1-Adam sweep -- 32 bytes per element per step, the reference's semantics -- would dominate the step.  Rides on the
+        # sparse-row path; `_has_slots` = "m / v tables and beta powers exist" (both Adam flavours)
+        self._lazy_adam = self.opt_method in ("LazyAdam", "lazyadam", "lazy_adam")
+        self._has_slots = self._adam or self._lazy_adam
         # TransE: exact integer sign-count gradients instead of fp32 atomics (include/kge_mi355.h)
         n_neg = self.negative_ent + self.negative_rel
         self.use_counts = bool(getattr(self, "use_counts", True)) and bool(
@@ -275,11 +280,13 @@ class Config(object):
             if threshold is None:
                 threshold = max(128 << 20, int(0.3 * touched_bytes))
             sparse = table_bytes > int(threshold)
-        self.sparse_rows = bool(sparse) and self.use_counts and not self._adam
+        self.sparse_rows = (bool(sparse) or self._lazy_adam) and self.use_counts and not self._adam
         if requested and not self.sparse_rows:
-            raise KgeError("sparse_rows needs TransE (sign-count path: 1..63 negatives) with SGD")
+            raise KgeError("sparse_rows needs TransE (sign-count path: 1..63 negatives) with SGD or LazyAdam")
+        if self._lazy_adam and not self.sparse_rows:
+            raise KgeError("LazyAdam (touched rows only, NON-PARITY) needs TransE on the sign-count path: 1..63 negatives")
         self._grads = [] if self.sparse_rows else [torch.zeros_like(t) for t in self._tables]
-        if self._adam:
+        if self._has_slots:
             self._adam_m = [torch.zeros_like(t) for t in self._tables]
             self._adam_v = [torch.zeros_like(t) for t in self._tables]
             self._beta1_power = np.float32(self.adam_beta1)
@@ -358,6 +365,8 @@ class Config(object):
         self._n_local = self.lib.kge_slice_positions(self.batch_size, lo, hi, ctypes.byref(first))
         self._first_pos = first.value
         if self._dp and self.trainModel is not None and getattr(self, "_dist_ready", 0) != self.world_size:
+            if getattr(self, "_lazy_adam", False):
+                raise KgeError("LazyAdam is single-process (the sharded path keeps no moment shards)")
             if self.sparse_rows:
                 self._setup_shards()
             else:
@@ -380,7 +389,7 @@ class Config(object):
         self._tab_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._tables])
         self._grad_ptrs = _lib.table_ptrs([g.data_ptr() for g in self._grads])
         self._numel = (ctypes.c_int64 * _lib.KGE_MAX_TABLES)(*[t.numel() for t in self._tables])
-        if self._adam:
+        if self._has_slots:
             self._adam_m_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._adam_m])
             self._adam_v_ptrs = _lib.table_ptrs([t.data_ptr() for t in self._adam_v])
 
@@ -834,7 +843,17 @@ class Config(object):
                 raise KgeError("sparse_rows: %d groups have negatives that are not single-slot corruptions of their "
                                "positive; train such batches with sparse_rows=False" % nd.value)
         rec, dst = buf["rec"], buf["dst"]
-        if getattr(self, "sparse_fused", True) and D % 4 == 0:
+        if self._lazy_adam:
+            _lib.check(self.lib.kge_transe_reduce_records(
+                ctypes.byref(self._desc), rec.data_ptr(), dst.data_ptr(), dst.numel(), buf["rows"].data_ptr(),
+                buf["row_counts"].data_ptr(), buf["n_rows"].data_ptr(), st), self.lib)
+            _lib.check(self.lib.kge_transe_apply_rows_adam_lazy(
+                ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(), self._adam_m[0].data_ptr(),
+                self._adam_m[1].data_ptr(), self._adam_v[0].data_ptr(), self._adam_v[1].data_ptr(), buf["rows"].data_ptr(),
+                buf["row_counts"].data_ptr(), buf["n_rows"].data_ptr(), dst.numel(), denom, float(self._adam_lr_t()),
+                self.adam_beta1, self.adam_beta2, self.adam_epsilon, st), self.lib)
+            self._adam_advance()
+        elif getattr(self, "sparse_fused", True) and D % 4 == 0:
             # reduce + apply in one pass: only chunk-boundary rows go through the compact count image
             _lib.check(self.lib.kge_transe_reduce_apply_records_sgd(
                 ctypes.byref(self._desc), rec.data_ptr(), dst.data_ptr(), dst.numel(), self._tables[0].data_ptr(),

@@ -93,6 +93,7 @@ def _declare(L):
     L.kge_transe_emit_records.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.kge_transe_reduce_records.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, i64, vp, vp, vp, vp]
     L.kge_transe_apply_rows_sgd.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i64, f32, vp]
+    L.kge_transe_apply_rows_adam_lazy.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, f32, f32, f32, vp]
     L.kge_transe_reduce_apply_records_sgd.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, i64, vp, vp, vp, vp, vp, i64, f32, vp]
     L.kge_transe_apply_counts_range.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i64, i64, i32, f32, f32, f32, f32, vp]
     L.kge_transe_set_bf16_shadow.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp]

@@ -1054,6 +1054,7 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
         touched = team_sum<L>(touched);
         if (touched == 0.f && !a.adam) continue;  // SGD leaves untouched rows alone; TF1 Adam moves every row
         if (!every_row) tm.load(table, row, x);
+        if (SPARSE && a.adam) { tm.load(mt, row, m_old); tm.load(vt, row, v_old); }   // lazy Adam: the listed rows only
         if (touched != 0.f) {
             float xn[C], inv; bool uc;
             tm.normalize(x, xn, inv, uc);
@@ -1073,7 +1074,7 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
             xnew[c] = 0.f;
             if (e >= a.D) continue;
             float pn = x[c];
-            if (!SPARSE && a.adam) {
+            if (a.adam) {
                 float *mp = mt + row * a.D + e, *vp = vt + row * a.D + e;
                 float mi = __fmul_rn(m_old[c], a.b1), vi = __fmul_rn(v_old[c], a.b2);
                 if (g[c] != 0.f) {
@@ -1083,7 +1084,7 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
                 *mp = mi; *vp = vi;
                 pn = __fsub_rn(x[c], __fdiv_rn(__fmul_rn(a.lr, mi), __fadd_rn(__fsqrt_rn(vi), a.eps)));
                 pp[e] = pn;
-                if (sh) sh[row * a.D + e] = bf16_rne(pn);
+                if (!SPARSE && sh) sh[row * a.D + e] = bf16_rne(pn);
             } else if (g[c] != 0.f) {
                 pn = __fsub_rn(x[c], __fmul_rn(a.lr, g[c]));
                 pp[e] = pn;
@@ -1363,6 +1364,31 @@ int kge_transe_apply_rows_sgd(const kge_model_desc *m, float *d_ent, float *d_re
     KGE_SHAPE_DISPATCH(D, KGE_RAPPLY)
 #undef KGE_RAPPLY
     return hip_check(hipGetLastError(), "apply rows launch");
+}
+
+int kge_transe_apply_rows_adam_lazy(const kge_model_desc *m, float *d_ent, float *d_rel, float *d_m_ent, float *d_m_rel, float *d_v_ent,
+                                    float *d_v_rel, const int32_t *d_rows, const int32_t *d_row_counts, const int32_t *d_n_rows,
+                                    INT max_rows, INT denom, float lr_t, float beta1, float beta2, float eps, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_apply_rows_adam_lazy: no usable HIP device");
+    if (!m || !d_ent || !d_rel || !d_m_ent || !d_m_rel || !d_v_ent || !d_v_rel || !d_rows || !d_row_counts || !d_n_rows || denom <= 0)
+        return fail(KGE_ERR_BAD_ARG, "kge_transe_apply_rows_adam_lazy: bad arguments");
+    tables_written();
+    if (max_rows <= 0) return KGE_OK;
+    ApplyArgs a = {};
+    a.p = d_ent; a.p2 = d_rel; a.m = d_m_ent; a.m2 = d_m_rel; a.v = d_v_ent; a.v2 = d_v_rel;
+    a.row_list = d_rows; a.S = const_cast<int32_t *>(d_row_counts); a.n_rows = d_n_rows;
+    a.E = m->ent_total; a.D = m->ent_dim; a.unit = 1.0f / (float)denom; a.lr = lr_t; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.adam = 1;
+    const int D = m->ent_dim;
+#define KGE_RLAZY(LL, CC)                                                                                   \
+    {                                                                                                       \
+        long long nb = (max_rows + (256 / LL) - 1) / (256 / LL);                                            \
+        if (nb > 8192) nb = 8192;                                                                           \
+        hipLaunchKernelGGL((apply_counts_kernel<LL, CC, true>), dim3((unsigned)nb), dim3(256), 0, stream, a); \
+    }
+    KGE_SHAPE_DISPATCH(D, KGE_RLAZY)
+#undef KGE_RLAZY
+    return hip_check(hipGetLastError(), "lazy adam rows launch");
 }
 
 int kge_transe_apply_counts(float *d_p, float *d_m, float *d_v, int32_t *d_counts, float *d_resid, int64_t rows, int32_t dim,

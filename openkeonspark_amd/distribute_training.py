@@ -135,7 +135,7 @@ def checkpoint_arrays(con):
         out = {n: t.detach().cpu().numpy() for n, t in con.trainModel.parameter_lists.items() if n != "ent_embeddings"}
     else:
         out = dict(con.get_parameters())
-    if con._adam:
+    if con._has_slots:
         for name, m, v in zip(con.trainModel.table_names, con._adam_m, con._adam_v):
             out[name + "/Adam"] = m.detach().cpu().numpy()
             out[name + "/Adam_1"] = v.detach().cpu().numpy()
@@ -252,10 +252,10 @@ def restore_checkpoint(con, path, allow_growth=True, arrays=None):
                 raise ValueError("checkpoint table %s has %d rows, model needs %d" % (name, tab.shape[0], rows))
             tab = grow_table(tab, rows, rng)
         con.set_parameters_by_name(name, tab)
-        if con._adam and name + "/Adam" in z:
+        if con._has_slots and name + "/Adam" in z:
             con._adam_m[i].copy_(torch.from_numpy(grow_table(z[name + "/Adam"], rows, rng, zeros=True)))
             con._adam_v[i].copy_(torch.from_numpy(grow_table(z[name + "/Adam_1"], rows, rng, zeros=True)))
-    if con._adam and "beta1_power" in z:
+    if con._has_slots and "beta1_power" in z:
         con._beta1_power = np.float32(z["beta1_power"])
         con._beta2_power = np.float32(z["beta2_power"])
     con.global_step = int(z.get("global_step", 0))

@@ -794,3 +794,59 @@ def test_pair_count_path_shapes(model, E, R, D, B, n):
     finally:
         L.kge_set_option(b"float_records_min", 1 << 16)
         L.kge_set_option(b"pair_counts_min_neg", 0)
+
+
+def test_lazy_adam_moves_the_touched_rows_only():
+    """opt_method "LazyAdam" -- opt-in and NON-PARITY: the reference trains with TF1's AdamOptimizer, which moves every row of
+    every table each step (distribute_training.py:95-101; the dense path above is the parity path).  The lazy rule
+    (tf.contrib.opt.LazyAdamOptimizer) applies the same element formula to the rows a step touches and leaves all other rows
+    and their moments alone.  Checked here against that rule written out in numpy on the oracle's gradient: rows outside the
+    touched set keep p, m, v bit for bit; touched rows move by what a gradient within 1e-5 of the oracle's produces."""
+    from parity_util import adam_step_fp64, adam_update_explained
+    from torch_ref import near_kink_rows
+    rng = np.random.default_rng(21)
+    E, R, D, B, n, alpha = 400, 9, 64, 96, 3, 0.01
+    params = oracle.init_params(oracle.MODEL_IDS["transe"], E, R, D, D, seed=8)
+    orc = oracle.Model("transe", E, R, D, D, margin=1.0, params=params)
+    con = make_engine("transe", E, R, D, n, 0, margin=1.0, opt="LazyAdam", alpha=alpha, params=params)
+    assert con.sparse_rows and con._lazy_adam and not con._adam
+    names = con.trainModel.table_names
+    moved_rows = 0
+    for step in range(4):
+        bh, bt, br = batch_without_ties(orc, lambda: rand_batch(rng, E, R, B, n, 0, distinct=True), B, n)
+        p0 = con.get_parameters()
+        m0 = {k: con._adam_m[i].cpu().numpy() for i, k in enumerate(names)}
+        v0 = {k: con._adam_v[i].cpu().numpy() for i, k in enumerate(names)}
+        orc.params = {k: v.copy() for k, v in p0.items()}
+        active = orc.hinge_margins(bh, bt, br, B, n) > 0           # [B, n]
+        loss_o, g_o = orc.grad(bh, bt, br, B, n)
+        touched = {"ent_embeddings": set(), "rel_embeddings": set()}
+        for b in np.nonzero(active.any(1))[0]:
+            idx = [b] + [b + B * (k + 1) for k in np.nonzero(active[b])[0]]
+            touched["ent_embeddings"] |= set(np.asarray(bh)[idx].tolist()) | set(np.asarray(bt)[idx].tolist())
+            touched["rel_embeddings"] |= set(np.asarray(br)[idx].tolist())
+        loss_g = con.train_step(bh, bt, br, None)
+        assert abs(loss_g - loss_o) <= 2e-5 * abs(loss_o)
+        p1 = con.get_parameters()
+        m1 = {k: con._adam_m[i].cpu().numpy() for i, k in enumerate(names)}
+        v1 = {k: con._adam_v[i].cpu().numpy() for i, k in enumerate(names)}
+        lr_t = float(oracle.adam_lr_t(alpha, 0.9, 0.999, step + 1))
+        kink, _ = near_kink_rows("transe", p0, bh, bt, br, B, n, D, D, tol=1e-6)
+        for k in names:
+            T = np.array(sorted(touched[k]), dtype=np.int64)
+            rest = np.setdiff1d(np.arange(p0[k].shape[0]), T)
+            # untouched rows: nothing moves, not even the moments (this is what TF1's dense Adam would NOT do)
+            np.testing.assert_array_equal(p1[k][rest], p0[k][rest], err_msg=k)
+            np.testing.assert_array_equal(m1[k][rest], m0[k][rest], err_msg=k)
+            np.testing.assert_array_equal(v1[k][rest], v0[k][rest], err_msg=k)
+            assert (g_o[k][rest] == 0).all()
+            # touched rows: the Adam element rule on the oracle's gradient (zero-gradient elements of a touched row decay too)
+            pT, mT, vT, gT = (a[T].astype(np.float64) for a in (p0[k], m0[k], v0[k], g_o[k]))
+            du_o = adam_step_fp64(pT, mT, vT, gT, lr_t, 0.9, 0.999, 1e-8)
+            skip = {int(np.searchsorted(T, r)) for r in kink[k] if r in touched[k]}
+            rep = adam_update_explained(p0[k][T], m0[k][T], v0[k][T], g_o[k][T], p1[k][T].astype(np.float64) - p0[k][T], du_o, lr_t,
+                                        skip_rows=skip)
+            assert rep["unexplained"].size == 0, (step, k, rep["unexplained"][:8])
+            moved_rows += len(T)
+    assert moved_rows > 0 and con.global_step == 4
+    parity_report("lazy_adam_touched_rows_only", touched_rows_checked=moved_rows, steps=4)

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--ent-exponent", type=float, default=0.8, help="Zipf exponent of entity popularity (0 = uniform)")
     ap.add_argument("--dense", action="store_true", help="dense count image instead of the sparse-row path")
+    ap.add_argument("--opt", default="SGD", help="SGD | Adam (TF1 dense sweep, parity; implies --dense) | LazyAdam (touched rows only, NON-PARITY)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -45,9 +46,9 @@ def main():
     con.set_rel_neg_rate(0)
     con.set_alpha(0.01)
     con.set_margin(1.0)
-    con.set_opt_method("SGD")
+    con.set_opt_method(a.opt)
     con.set_nbatches(max(1, a.triples // a.batch))
-    con.sparse_rows = not a.dense
+    con.sparse_rows = False if a.opt == "Adam" else not a.dense
     t0 = time.time()
     con.init_from_arrays(a.entities, a.relations, h, t, r)
     t_index = time.time() - t0
@@ -65,8 +66,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.time() - t0
     B = con.batch_size
-    print(json.dumps({"workload": "synthetic KG %dM entities / %dM triples TransE dim=%d SGD %d neg/pos, %s" % (
-        a.entities // 1_000_000, a.triples // 1_000_000, a.dim, a.neg, "dense image" if a.dense else "sparse rows"),
+    print(json.dumps({"workload": "synthetic KG %dM entities / %dM triples TransE dim=%d %s %d neg/pos, %s" % (
+        a.entities // 1_000_000, a.triples // 1_000_000, a.dim, a.opt, a.neg, "dense image" if (a.dense or a.opt == "Adam") else "sparse rows"),
         "ent_exponent": a.ent_exponent, "batch": B, "ms_per_step": 1e3 * dt / a.steps, "positives_per_s": B * a.steps / dt, "loss": float(loss.item()),
         "hbm_allocated_GB": torch.cuda.max_memory_allocated() / 1e9,
         "seconds": {"generate": round(t_gen, 1), "index": round(t_index, 1), "table_init": round(t_init, 1)}}))
