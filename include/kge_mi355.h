@@ -243,6 +243,17 @@ int kge_forward_backward(const kge_model_desc *m, const float *const tables[KGE_
  * kernels that follow (bucketing, segmented sum, apply).  Returns KGE_NO_EVENT (and makes `stream` wait for nothing) when no
  * emit launch was recorded since the previous call: the caller then orders `stream` behind the step by an event of its own. */
 int kge_stream_wait_emit(void *stream);
+/* Forward / backward AND plain SGD on the touched rows only, in place (TransE / TransH / TransD): the step's gradient rows are
+ * stored as float records, ordered by destination row, summed by segments and added to their PARAMETER rows as -lr * sum.
+ * No gradient tables and no sweep over the tables: for tables whose size, not the batch, would set the step time (the dense
+ * form is kge_forward_backward + kge_sgd_update_tables; same update up to fp32 summation order -- GradientDescentOptimizer
+ * leaves rows without gradient alone, distribute_training.py:99-101).  Not for Adam: TF1's Adam moves every row.
+ * Negatives that are not single-slot corruptions of their positive (the reference's sampler draws no others; a hand-fed batch
+ * may hold them) are SKIPPED -- their exact path adds rows atomically, which in place would race with the forward reads -- and
+ * counted: kge_sgd_rows_skipped (synchronises); the caller must treat a non-zero count as an error of that step. */
+int kge_forward_backward_sgd_rows(const kge_model_desc *m, float *const tables[KGE_MAX_TABLES], const int32_t *d_h, const int32_t *d_t,
+                                  const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom, float lr, float *d_loss, void *stream);
+int kge_sgd_rows_skipped(int32_t *n_negatives);
 /* 1 when kge_forward_backward on a step of this shape takes the TransH / TransD pair-count path (whose emit kernel also records
  * the event above), else 0 */
 int kge_pair_path_active(const kge_model_desc *m, INT n_pos, INT n_neg);

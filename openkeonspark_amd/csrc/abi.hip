@@ -380,6 +380,18 @@ int kge_forward_backward(const kge_model_desc *m, const float *const tables[KGE_
     return launch_forward_backward(*m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, grads, d_loss, (hipStream_t)stream, false);
 }
 
+int kge_forward_backward_sgd_rows(const kge_model_desc *m, float *const tables[KGE_MAX_TABLES], const int32_t *d_h, const int32_t *d_t,
+                                  const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom, float lr, float *d_loss, void *stream) {
+    if (!m || !tables || !d_loss) return fail(KGE_ERR_BAD_ARG, "kge_forward_backward_sgd_rows: null argument");
+    if (!(lr > 0.f)) return fail(KGE_ERR_BAD_ARG, "kge_forward_backward_sgd_rows: learning rate must be positive");
+    return launch_forward_backward(*m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, tables, d_loss, (hipStream_t)stream, false, lr);
+}
+
+int kge_sgd_rows_skipped(int32_t *n_negatives) {
+    if (!n_negatives) return fail(KGE_ERR_BAD_ARG, "kge_sgd_rows_skipped: null argument");
+    return sgd_rows_skipped(n_negatives);
+}
+
 int kge_pair_path_active(const kge_model_desc *m, INT n_pos, INT n_neg) { return m && pair_path_active(*m, n_pos, n_neg) ? 1 : 0; }
 
 int kge_stream_wait_emit(void *stream) {

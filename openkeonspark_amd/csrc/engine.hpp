@@ -134,8 +134,10 @@ struct FloatRowSpace {   // virtual row space of models.hip's FbArgs::frec recor
     long long E, R;             // entity rows [0,E), ent_transfer rows [E, hub_base) when hub_base == 2E
     long long hub_base, hub_rows;   // copies of { rel [R] | auxr [R] } from hub_base on, hub_rows rows per copy
     long long rows;             // total virtual rows
+    float scale = 1.0f;         // a run's sum is added as scale * sum (-lr with the PARAMETER tables as targets: sparse-row SGD in place)
 };
 bool pair_path_active(const kge_model_desc &m, int64_t n_pos, int64_t n_neg);
+int sgd_rows_skipped(int32_t *out);
 int float_records_workspace(int64_t M, int D, float *&rec, int32_t *&dst);
 int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t stream);
 
@@ -150,7 +152,7 @@ int launch_sampler(int32_t *d_h, int32_t *d_t, int32_t *d_r, int64_t B, int64_t 
 int launch_widen(const int32_t *src3, int64_t *dst3_and_y, int64_t B, int64_t total, hipStream_t stream);
 int launch_forward_backward(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
                             const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride, int64_t denom,
-                            float *const grads[4], float *d_loss, hipStream_t stream, bool sampler_shaped = false);
+                            float *const grads[4], float *d_loss, hipStream_t stream, bool sampler_shaped = false, float inplace_lr = 0.f);
 int launch_predict(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
                    const int32_t *d_r, int64_t n, float *d_out, hipStream_t stream);
 int launch_lp_table(const kge_model_desc &m, const float *const tables[4], const float *P_all, int64_t r, float *T, hipStream_t stream);

@@ -587,6 +587,13 @@ static int32_t *g_defer_list = nullptr, *g_defer_count = nullptr;
 static int64_t g_defer_cap = 0;
 
 // groups of the LAST emit launch that were not sampler-shaped (synchronous read of the device counter)
+static int32_t *g_skipped = nullptr;     // negatives the last in-place SGD step skipped (FbArgs::skipped)
+int sgd_rows_skipped(int32_t *out) {
+    *out = 0;
+    if (!g_skipped) return KGE_OK;
+    return hip_check(hipMemcpy(out, g_skipped, sizeof(int32_t), hipMemcpyDeviceToHost), "read skipped-negatives counter");
+}
+
 int transe_deferred_groups(int32_t *out) {
     *out = 0;
     if (!g_defer_count) return KGE_OK;
@@ -1018,13 +1025,18 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
 
 int launch_forward_backward(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
                             const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride, int64_t denom,
-                            float *const grads[4], float *d_loss, hipStream_t stream, bool sampler_shaped) {
+                            float *const grads[4], float *d_loss, hipStream_t stream, bool sampler_shaped, float inplace_lr) {
+    // inplace_lr != 0 (kge_forward_backward_sgd_rows): `grads` ARE the parameter tables; the step's gradient rows go through the
+    // float-record path whatever its size and every summed run is added to its row as -lr * sum -- SGD on the touched rows, no
+    // gradient tables, no sweep.  The forward has finished reading the tables when the segmented sum starts (one stream).
     Engine &e = engine();
     if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_forward_backward: no usable HIP device");
     if (n_pos < 0 || n_neg < 1 || stride < n_pos || denom <= 0) return fail(KGE_ERR_BAD_ARG, "kge_forward_backward: bad sizes");
     { int rc = ensure_loss_buffers(); if (rc) return rc; }
-    if (m.model == KGE_TRANSR)
+    if (m.model == KGE_TRANSR) {
+        if (inplace_lr != 0.f) return fail(KGE_ERR_UNSUPPORTED, "row-wise SGD in place: TransE / TransH / TransD only");
         return launch_forward_backward_transr(m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, grads, d_loss, stream, sampler_shaped);
+    }
     if (m.ent_dim != m.rel_dim) return fail(KGE_ERR_BAD_ARG, "TransE/H/D need ent_dim == rel_dim (hidden_size)");
     FbArgs a = {};
     a.ent = tables[0]; a.rel = tables[1]; a.auxr = tables[2]; a.auxe = tables[3];
@@ -1036,7 +1048,7 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
     a.P = nullptr; a.GP = nullptr; a.negative_rel = m.negative_rel;
     int rc;
     // Pair-count path (TransH / TransD): int8 sign records keyed by (entity, relation), the backward applied once per pair
-    if (pair_path_active(m, n_pos, n_neg)) {
+    if (inplace_lr == 0.f && pair_path_active(m, n_pos, n_neg)) {     // (its per-pair backward re-reads the rows: not for in-place updates)
         const int64_t M = n_pos * (2 + n_neg);
         const int rd = pair_record_dwords(a.D);
         if ((rc = pair_records_workspace(M, rd, a.rec, a.dst, a.pair_aux))) return rc;
@@ -1094,13 +1106,21 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
     if (hub_k < 1) hub_k = 1;
     if (hub_k > 4096) hub_k = 4096;
     const int64_t rows = ent_rows + hub_k * hub_rows;
-    if (e.float_records && M >= e.float_records_min && M < (int64_t(1) << 31) && rows < (int64_t(1) << 31) - 1 && a.D <= 1024) {
+    const bool records_fit = M < (int64_t(1) << 31) && rows < (int64_t(1) << 31) - 1 && a.D <= 1024;
+    if (inplace_lr != 0.f && !records_fit) return fail(KGE_ERR_UNSUPPORTED, "row-wise SGD in place: step or row space too large for the record sort");
+    if (n_pos == 0 && inplace_lr != 0.f) return hip_check(hipMemsetAsync(d_loss, 0, sizeof(float), stream), "zero loss");
+    if (records_fit && (inplace_lr != 0.f || (e.float_records && M >= e.float_records_min))) {
         float *frec = nullptr;
         int32_t *fdst = nullptr;
         if ((rc = float_records_workspace(M, a.D, frec, fdst))) return rc;
         a.frec = frec; a.fdst = fdst;
         a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total;
         a.hub_base = ent_rows; a.hub_k = (int)hub_k; a.hub_rows = (int)hub_rows;
+        if (inplace_lr != 0.f) {
+            if (!g_skipped && (rc = hip_check(hipMalloc(&g_skipped, sizeof(int32_t)), "alloc skipped-negatives counter"))) return rc;
+            if ((rc = hip_check(hipMemsetAsync(g_skipped, 0, sizeof(int32_t), stream), "zero skipped-negatives counter"))) return rc;
+            a.skipped = g_skipped;
+        }
         switch (m.model) {
             case KGE_TRANSE: rc = dispatch_fb_records<KGE_TRANSE>(a, d_loss, stream); break;
             case KGE_TRANSH: rc = dispatch_fb_records<KGE_TRANSH>(a, d_loss, stream); break;
@@ -1111,6 +1131,7 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
         FloatRowSpace rs;
         rs.g_ent = grads[0]; rs.g_rel = grads[1]; rs.g_auxr = grads[2]; rs.g_auxe = grads[3];
         rs.E = m.ent_total; rs.R = m.rel_total; rs.hub_base = ent_rows; rs.hub_rows = hub_rows; rs.rows = rows;
+        if (inplace_lr != 0.f) { rs.scale = -inplace_lr; tables_written(); }
         return float_records_reduce(M, a.D, rs, stream);
     }
     // atomic path: hub copies for the relation-side rows when a row would take hundreds of adds per step

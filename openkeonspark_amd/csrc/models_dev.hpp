@@ -47,6 +47,9 @@ struct FbArgs {
     // pair-count path (pairs.hip): per record the projection coefficient a and 1/|projected| of its (entity, relation) pair
     // (negative 1/|.| = the norm was clipped), so that the per-pair backward need not recompute them
     float2 *pair_aux;
+    // row-wise SGD in place (kge_forward_backward_sgd_rows): the accumulators ARE the parameter tables, so a negative that is not a
+    // single-slot corruption (its exact path adds rows atomically) must not run: it is skipped and counted here
+    int32_t *skipped;
 };
 
 int ensure_loss_buffers();
@@ -358,7 +361,8 @@ __device__ __forceinline__ void fwdbwd_group(const Team<L, C> &tm, const FbArgs 
         bool wrote = false;
         if (!nc.fast) {
             float hinge;
-            if (standalone_negative<MODEL, L, C>(tm, a, nrow_h, nrow_t, nr, p, hinge)) { cnt++; lsum += hinge; }
+            if (a.skipped) { if (tm.lane == 0) atomicAdd(a.skipped, 1); }
+            else if (standalone_negative<MODEL, L, C>(tm, a, nrow_h, nrow_t, nr, p, hinge)) { cnt++; lsum += hinge; }
             if (REC && tm.lane == 0) {
 #pragma unroll
                 for (int w = 0; w < RS::ent_w; w++) a.fdst[m_neg + w * a.n_pos] = -1;

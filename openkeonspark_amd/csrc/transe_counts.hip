@@ -584,8 +584,9 @@ __device__ __forceinline__ void flush_run_f32(const FloatRowSpace &rs, int D, in
     for (int c = 0; c < C; c++) {
         const int e = lane + L * c;
         if (e < D) {
-            if (atomic) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(p + e), acc[c]);
-            else p[e] += acc[c];
+            const float v = __fmul_rn(rs.scale, acc[c]);
+            if (atomic) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(p + e), v);
+            else p[e] += v;
         }
     }
 }

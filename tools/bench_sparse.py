@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--ent-exponent", type=float, default=0.8, help="Zipf exponent of entity popularity (0 = uniform)")
     ap.add_argument("--dense", action="store_true", help="dense count image instead of the sparse-row path")
+    ap.add_argument("--model", default="TransE", help="TransE | TransH | TransD (the latter two: --dense = gradient tables + sweep, else row-wise SGD in place)")
     ap.add_argument("--opt", default="SGD", help="SGD | Adam (TF1 dense sweep, parity; implies --dense) | LazyAdam (touched rows only, NON-PARITY)")
     a = ap.parse_args()
     import numpy as np
@@ -54,7 +55,7 @@ def main():
     t_index = time.time() - t0
     del h, t, r
     t0 = time.time()
-    con.set_model_and_session(ok.TransE)
+    con.set_model_and_session(getattr(ok, a.model))
     torch.cuda.synchronize()
     t_init = time.time() - t0
     for _ in range(a.warmup):
@@ -66,8 +67,9 @@ def main():
     torch.cuda.synchronize()
     dt = time.time() - t0
     B = con.batch_size
-    print(json.dumps({"workload": "synthetic KG %dM entities / %dM triples TransE dim=%d %s %d neg/pos, %s" % (
-        a.entities // 1_000_000, a.triples // 1_000_000, a.dim, a.opt, a.neg, "dense image" if (a.dense or a.opt == "Adam") else "sparse rows"),
+    print(json.dumps({"workload": "synthetic KG %dM entities / %dM triples %s dim=%d %s %d neg/pos, %s" % (
+        a.entities // 1_000_000, a.triples // 1_000_000, a.model, a.dim, a.opt, a.neg,
+        "dense image / gradient tables + sweep" if (a.dense or a.opt == "Adam") else "sparse rows"),
         "ent_exponent": a.ent_exponent, "batch": B, "ms_per_step": 1e3 * dt / a.steps, "positives_per_s": B * a.steps / dt, "loss": float(loss.item()),
         "hbm_allocated_GB": torch.cuda.max_memory_allocated() / 1e9,
         "seconds": {"generate": round(t_gen, 1), "index": round(t_index, 1), "table_init": round(t_init, 1)}}))
