@@ -461,6 +461,9 @@ class Config(object):
         self._own_len = own
         self._grads_own = torch.zeros(chunk, dtype=torch.float32, device=dev)
         self._loss_tail = total - 1                           # spare element (no table reaches it) of the LAST rank's last piece
+        # the loss scalar LIVES in that slot: the step's kernels write this rank's partial loss there, the exchange replaces it by
+        # the global one (no copy in either direction)
+        self._loss = flat_p[self._loss_tail:]
         if self.use_counts:
             rows_total = chunk_rows * W
             seg_r, own_r = rows_total // K, chunk_rows // K
@@ -662,7 +665,7 @@ class Config(object):
                     _lib.check(self.lib.kge_limbs_to_loss(flat_own[flat_own.numel() - self.hidden_size:].data_ptr(),
                                                           self._flat_p[self._loss_tail:].data_ptr(), st), self.lib)
                 else:
-                    self._flat_p[self._loss_tail:].copy_(flat_own[-1:])
+                    self._loss.copy_(flat_own[-1:])
             apply_piece(k)
             (slo, shi), (lo, hi) = self._piece_seg[k], self._piece_own[k]
             ag.append(all_gather_chunks(self._flat_p[slo:shi], self._flat_p[lo:hi], self._pg, async_op=True))
@@ -673,8 +676,7 @@ class Config(object):
         for w in ag:
             if w is not None:
                 w.wait()
-        if ride:
-            self._loss.copy_(self._flat_p[self._loss_tail:])
+        # (ride: self._loss IS the tail slot of the parameter buffer -- the all-gather has just delivered the global loss into it)
 
     def sync_optimizer_state(self):
         """Data-parallel Adam keeps m and v current on their owner only; gather them before they are read as whole tables

@@ -160,9 +160,6 @@ def _lp_worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    elif rccl_one_rank:     # a ONE-rank RCCL group: the collectives of the data-parallel step on device memory, as the 8-GPU run issues them
-        torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=0, world_size=1)
     import openkeonspark_amd as pkg
     con = pkg.Config()
     con.set_in_path(os.path.join(GOLDEN, "kg_small"))
@@ -325,9 +322,6 @@ def _config5_worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    elif rccl_one_rank:     # a ONE-rank RCCL group: the collectives of the data-parallel step on device memory, as the 8-GPU run issues them
-        torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=0, world_size=1)
     import openkeonspark_amd as pkg
     pkg._lib.lib().kge_set_option(b"inv_table_max_bytes", 0)
     rng = np.random.default_rng(5)
