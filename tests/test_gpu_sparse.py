@@ -168,10 +168,11 @@ def test_fused_reduce_apply_equals_two_stage(dim, n_neg):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("model,opt,n_neg", [("TransH", "SGD", 1), ("TransE", "Adam", 1), ("TransE", "SGD", 64)])
+@pytest.mark.parametrize("model,opt,n_neg", [("TransH", "Adam", 1), ("TransE", "Adam", 1), ("TransR", "SGD", 1)])
 def test_sparse_rows_request_that_cannot_be_honoured_raises(model, opt, n_neg):
-    """sparse_rows=True needs TransE on the sign-count path (1..63 negatives) with SGD; anything else must fail loudly instead of
-    silently allocating dense gradient / count / Adam images."""
+    """sparse_rows=True needs a touched-rows-only update: TransE / TransH / TransD with SGD (or TransE with the labelled LazyAdam).
+    TF1's Adam moves every row and TransR's matrices have no such path: those must fail loudly instead of silently allocating dense
+    gradient / count / Adam images."""
     import openkeonspark_amd as ok
     con = ok.Config()
     con.set_in_path(os.path.join(GOLD, "kg_tiny") + "/")
@@ -180,3 +181,20 @@ def test_sparse_rows_request_that_cannot_be_honoured_raises(model, opt, n_neg):
     con.init()
     with pytest.raises(ok.KgeError):
         con.set_model_and_session(getattr(ok, model))
+
+
+@pytest.mark.parametrize("model,n_neg", [("TransH", 1), ("TransD", 2), ("TransE", 64)])
+def test_sparse_rows_request_off_the_count_path_takes_the_in_place_row_update(model, n_neg):
+    """TransH / TransD -- and TransE with more negatives than the int8 records hold -- honour sparse_rows=True through
+    kge_forward_backward_sgd_rows: no gradient tables are allocated and sampled steps train (loss finite and falling)."""
+    import openkeonspark_amd as ok
+    con = ok.Config()
+    con.set_in_path(os.path.join(GOLD, "kg_tiny") + "/")
+    con.set_work_threads(2); con.set_nbatches(2); con.set_dimension(16); con.set_ent_neg_rate(n_neg); con.set_opt_method("SGD")
+    con.set_alpha(0.05)
+    con.sparse_rows = True
+    con.init()
+    con.set_model_and_session(getattr(ok, model))
+    assert con.sparse_inplace and not con.sparse_rows and con._grads == []
+    losses = [con.train_step() for _ in range(30)]
+    assert all(np.isfinite(losses)) and np.mean(losses[-5:]) < np.mean(losses[:5])
