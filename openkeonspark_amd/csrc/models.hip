@@ -860,10 +860,14 @@ __global__ __launch_bounds__(256) void transr_vec_kernel(FbArgs a) {
         const int h = a.bh[b], t = a.bt[b], r = a.br[b];
         // ---- every negative entity-corrupted, scored with the positive's matrix? ----
         float bad = 0.f;
+        int my_new_head = 0;      // lane k: does negative k (k < 64) replace the head?  Handed out by lane broadcast below, so that the
+                                  // negatives' row loads do not each wait for an id load of their own
         for (int k = lane; k < (int)a.n_neg; k += L) {
             const long long j = b + (long long)(k + 1) * a.stride;
-            const NegClass nc = classify_negative<KGE_TRANSR>(h, t, r, a.bh[j], a.bt[j], a.br[j], a.negative_rel);
+            const int nh = a.bh[j];
+            const NegClass nc = classify_negative<KGE_TRANSR>(h, t, r, nh, a.bt[j], a.br[j], a.negative_rel);
             if (!nc.fast || nc.same_h == nc.same_t) bad = 1.f;
+            if (k < L) my_new_head = nh != h ? 1 : 0;
         }
         if (team_sum<L>(bad) != 0.f) {
             // the generic kernel writes the rows of its active hinges; everything dgrad / wgrad may read of this group is zeroed first
@@ -876,7 +880,13 @@ __global__ __launch_bounds__(256) void transr_vec_kernel(FbArgs a) {
         }
         float rn[E], hn[E], tn[E];
         float inv_r, inv_h, inv_t; bool uc_r, uc_h, uc_t;
+        // negative k's projected row: requested one negative ahead (the first one together with the positive's three rows), so a
+        // row's memory round trip overlaps the reductions of the row before it
+        auto head_is_new = [&](long long k) { return k < L ? team_bcast<L>(my_new_head, (int)k) != 0 : a.bh[b + (k + 1) * a.stride] != h; };
+        float x_ahead[E];
+        bool nh_ahead = head_is_new(0);
         load(a.rel, r, rn); load(a.P, 2 * b, hn); load(a.P, 2 * b + 1, tn);
+        load(a.P, 2 * (a.n_pos + b) + (nh_ahead ? 0 : 1), x_ahead);
         normalize(rn, inv_r, uc_r); normalize(hn, inv_h, uc_h); normalize(tn, inv_t, uc_t);
         float sp[E], Ah[E], At[E], Ar[E];
         float p;
@@ -888,12 +898,16 @@ __global__ __launch_bounds__(256) void transr_vec_kernel(FbArgs a) {
         }
         int cnt = 0;
         for (long long k = 0; k < a.n_neg; k++) {
-            const long long j = b + (k + 1) * a.stride;
-            const bool new_head = a.bh[j] != h;
+            const bool new_head = nh_ahead;
             const long long slot = 2 * ((k + 1) * a.n_pos + b) + (new_head ? 0 : 1);   // the corrupted side's projected row
             float xn[E], sg[E];
             float inv; bool uc;
-            load(a.P, slot, xn);
+#pragma unroll
+            for (int e = 0; e < E; e++) xn[e] = x_ahead[e];
+            if (k + 1 < a.n_neg) {
+                nh_ahead = head_is_new(k + 1);
+                load(a.P, 2 * ((k + 2) * a.n_pos + b) + (nh_ahead ? 0 : 1), x_ahead);
+            }
             normalize(xn, inv, uc);
             float acc = 0.f;
 #pragma unroll
