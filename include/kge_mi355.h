@@ -273,6 +273,9 @@ int kge_forward_backward_sampled(const kge_model_desc *m, const float *const tab
  * the number of ranks or on the reduction order. */
 int kge_loss_to_limbs(const float *d_loss, int32_t *d_limbs4, void *stream);
 int kge_limbs_to_loss(const int32_t *d_limbs4, float *d_out, void *stream);
+/* From now on kge_transe_forward_counts on a device-sampled batch ALSO writes its loss as those four limbs to d_limbs4 (the emit
+ * kernel's last workgroup does it: no conversion launch); NULL switches it off.  The pointer must stay valid until then. */
+int kge_loss_limbs_target(int32_t *d_limbs4);
 
 /* GradientDescentOptimizer on the summed gradient: p -= lr*g; g = 0   (distribute_training.py:98) */
 int kge_sgd_update(float *d_p, float *d_g, int64_t n, float lr, void *stream);

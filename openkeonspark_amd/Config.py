@@ -647,7 +647,7 @@ class Config(object):
         ride = flat_img.numel() >= 4 and (not counts or self.hidden_size >= 4)
         last = self.rank == W - 1
         if ride:
-            if counts:
+            if counts and not getattr(self, "_limbs_from_emit", False):     # (a sampled batch: the emit kernel has written the limbs itself)
                 _lib.check(self.lib.kge_loss_to_limbs(self._loss.data_ptr(), flat_img[flat_img.numel() - self.hidden_size:].data_ptr(), st), self.lib)
             else:
                 flat_img[-1:].copy_(self._loss)
@@ -736,6 +736,12 @@ class Config(object):
             ahead = batch_h is None and self.prefetch_sampling
             if ahead:
                 self._attach_next_batch()              # rides in the scatter launch enqueued by forward_counts
+            # data-parallel: the emit kernel of a sampled batch also writes the loss as limbs into the count image's spare tail slot
+            self._limbs_from_emit = bool(self._dp and batch_h is None and self.hidden_size >= 4)
+            target = self._counts.view(-1)[self._counts.numel() - self.hidden_size:].data_ptr() if self._limbs_from_emit else 0
+            if target != getattr(self, "_limbs_target", 0):
+                self.lib.kge_loss_limbs_target(ctypes.c_void_p(target) if target else None)
+                self._limbs_target = target
             try:
                 self.forward_counts(dev, n_pos, stride, denom, sampler_shaped=batch_h is None)
             finally:

@@ -387,6 +387,11 @@ int kge_forward_backward_sgd_rows(const kge_model_desc *m, float *const tables[K
     return launch_forward_backward(*m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, tables, d_loss, (hipStream_t)stream, false, lr);
 }
 
+int kge_loss_limbs_target(int32_t *d_limbs4) {
+    engine().loss_limbs = d_limbs4;
+    return KGE_OK;
+}
+
 int kge_sgd_rows_skipped(int32_t *n_negatives) {
     if (!n_negatives) return fail(KGE_ERR_BAD_ARG, "kge_sgd_rows_skipped: null argument");
     return sgd_rows_skipped(n_negatives);

@@ -65,6 +65,7 @@ struct Engine {
     int64_t inv_cap = 0;
     const float *inv_for_ent = nullptr, *inv_for_rel = nullptr;
     int inv_valid = 0, inv_bf16 = 0;
+    int32_t *loss_limbs = nullptr;   // kge_loss_limbs_target: where the TransE emit kernel also writes its loss as limbs (null = nowhere)
     int counts_krel = 4;        // dense TransE path: virtual copies of the relation rows in the record sort (1 = none; measured 1/2/4/8/16/64: 4 best); a power of two
     int inv_carry = 1;          // 0 = always recompute the table in front of the emit kernel (test hook)
     int64_t inv_table_max_bytes = int64_t(256) << 20;  // TransE emit: per-row inverse-norm table only while the tables are this small

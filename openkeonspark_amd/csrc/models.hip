@@ -642,6 +642,7 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
     a.loss_partials = e.dev.loss_partials;
     a.negative_rel = m.negative_rel;
     a.rec = rec; a.dst = dst; a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total; a.krel = 1;
+    a.loss_limbs = track_deferred ? nullptr : e.loss_limbs;   // (with a deferred pass the loss is finalised by loss_finalize_kernel: the caller converts it)
     while (a.krel * 2 <= krel) a.krel *= 2;      // a power of two: the kernels take b & (krel - 1)
     const int D = a.D;
     if (D % 4 == 0 && D <= 64) launch_emit<16, 4>(a, d_loss, stream);

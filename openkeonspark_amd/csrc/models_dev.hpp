@@ -50,6 +50,9 @@ struct FbArgs {
     // row-wise SGD in place (kge_forward_backward_sgd_rows): the accumulators ARE the parameter tables, so a negative that is not a
     // single-slot corruption (its exact path adds rows atomically) must not run: it is skipped and counted here
     int32_t *skipped;
+    // data-parallel TransE count path: the loss also goes out as four 16-bit limbs of a 2^-32 fixed-point value, into the spare tail
+    // slot of the int32 count image that the reduce-scatter sums (kge_loss_limbs_target; same encoding as kge_loss_to_limbs)
+    int32_t *loss_limbs;
 };
 
 int ensure_loss_buffers();
@@ -109,6 +112,11 @@ __device__ __forceinline__ void finish_loss(const FbArgs &a, float *red, float l
     }
     if (threadIdx.x == 0) {
         a.loss_out[0] = sh[0] * a.unit;
+        if (a.loss_limbs) {
+            const double x = (double)(sh[0] * a.unit) * 4294967296.0;
+            const long long v = x >= 0.0 ? (long long)(x + 0.5) : 0;
+            for (int i = 0; i < 4; i++) a.loss_limbs[i] = (int32_t)((v >> (16 * i)) & 0xFFFF);
+        }
         __hip_atomic_store(a.loss_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
