@@ -646,6 +646,28 @@ class Config(object):
         per_seg, per_own = flat_img.numel() // K, flat_own.numel() // K
         ride = flat_img.numel() >= 4 and (not counts or self.hidden_size >= 4)
         last = self.rank == W - 1
+        nat = self._stream_rccl() if (K == 1 and ride) else None
+        if nat is not None:
+            # one piece (tables below 64 MB): the two collectives go onto the engine's own stream, in order with its kernels
+            # (parallel.StreamRccl) -- no process-group stream, no event hand-offs
+            if counts and not getattr(self, "_limbs_from_emit", False):
+                _lib.check(self.lib.kge_loss_to_limbs(self._loss.data_ptr(), flat_img[flat_img.numel() - self.hidden_size:].data_ptr(), st), self.lib)
+            elif not counts:
+                flat_img[-1:].copy_(self._loss)
+            nat.reduce_scatter_sum(flat_own, flat_img, st)
+            if last:
+                if counts:
+                    _lib.check(self.lib.kge_limbs_to_loss(flat_own[flat_own.numel() - self.hidden_size:].data_ptr(), self._loss.data_ptr(), st), self.lib)
+                else:
+                    self._loss.copy_(flat_own[-1:])
+            apply_piece(0)
+            (slo, shi), (lo, hi) = self._piece_seg[0], self._piece_own[0]
+            nat.all_gather_chunks(self._flat_p[slo:shi], self._flat_p[lo:hi], st)
+            image.zero_()
+            if self._adam:
+                self._adam_advance()
+            self.global_step += 1
+            return
         if ride:
             if counts and not getattr(self, "_limbs_from_emit", False):     # (a sampled batch: the emit kernel has written the limbs itself)
                 _lib.check(self.lib.kge_loss_to_limbs(self._loss.data_ptr(), flat_img[flat_img.numel() - self.hidden_size:].data_ptr(), st), self.lib)
@@ -677,6 +699,31 @@ class Config(object):
             if w is not None:
                 w.wait()
         # (ride: self._loss IS the tail slot of the parameter buffer -- the all-gather has just delivered the global loss into it)
+
+    def _stream_rccl(self):
+        """The communicator for collectives on the engine's stream (parallel.StreamRccl): "nccl" backend, `stream_rccl` not switched
+        off.  Created on first use -- collectively: every rank reaches the first data-parallel step together."""
+        if getattr(self, "_nat_rccl", None) is None:
+            import torch.distributed as dist
+            want = getattr(self, "stream_rccl", True) and dist.is_initialized() and dist.get_backend(self._pg) == "nccl"
+            nat = False
+            if want:
+                import sys
+                import torch
+                from .parallel import StreamRccl
+                try:
+                    nat = StreamRccl(self._pg)
+                except Exception as exc:       # still RCCL either way: the process-group path is the documented alternative
+                    print("StreamRccl unavailable (%s): collectives stay on the process group's stream" % exc, file=sys.stderr)
+                # every rank must take the same path (a rank on the other communicator would wait for ever): agree on the minimum
+                ok = torch.tensor([1 if nat else 0], dtype=torch.int32, device=self.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self._pg)
+                if int(ok.item()) == 0:
+                    if nat:
+                        nat.close()
+                    nat = False
+            self._nat_rccl = nat
+        return self._nat_rccl or None
 
     def sync_optimizer_state(self):
         """Data-parallel Adam keeps m and v current on their owner only; gather them before they are read as whole tables

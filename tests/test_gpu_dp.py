@@ -49,6 +49,8 @@ def _worker(rank, world, port, out_dir, model_name, opt, sparse=False, prefetch=
             assert con._pieces == pieces
     if rccl_one_rank:
         assert con._dp and dist.get_backend() == "nccl" and (sparse or hasattr(con, "_flat_p"))
+        if not sparse and not pieces:       # one piece: the collectives run on the engine's own stream (parallel.StreamRccl)
+            assert con._stream_rccl() is not None
     losses = [con.train_step() for _ in range(4)]
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, "w%d_r%d%s.npz" % (world, rank, "_rccl" if rccl_one_rank else "")), losses=np.array(losses),
