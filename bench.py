@@ -311,6 +311,9 @@ def main():
         backend_name = dist.get_backend()
         if backend_name == "nccl":
             backend_name = "nccl (RCCL on ROCm)"
+    # where the step's reduce-scatter / all-gather were enqueued (openkeonspark_amd/parallel.py StreamRccl)
+    collective_stream = "none" if not getattr(con, "_dp", False) else (
+        "the engine's stream (own RCCL communicator, %d ranks)" % con._nat_rccl.world if getattr(con, "_nat_rccl", None) else "the process group's stream")
     # the kernel-duration sample must not depend on how few steps the caller timed: keep stepping (outside the timed
     # region, same training run) until at least 50 launches carry an event pair
     ms = ctypes.c_float()
@@ -350,7 +353,7 @@ def main():
             "value": B * args.steps / dt,
             "unit": "positive triples/s",
             "n_gpus": world, "world_size": dist.get_world_size() if use_dist else 1, "backend": backend_name,
-            "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
+            "rccl_ranks": rccl_ranks, "collective_stream": collective_stream, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 row gathers, f32 arithmetic / master tables / Adam slots (NON-PARITY fast mode)" if bf16 else "f32",
