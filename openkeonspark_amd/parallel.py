@@ -131,6 +131,9 @@ def exchange_counts(send_counts, group=None):
     return both[0].tolist(), both[1].tolist()
 
 
+_A2A_MAX_BYTES = 1 << 30      # per-peer message size above which all_to_all_rows slices the payload (see there)
+
+
 def all_to_all_rows(out, inp, recv_counts, send_counts, group=None):
     """Variable-size all-to-all along dim 0: rows [sum(send[:p]), sum(send[:p+1])) of `inp` go to peer p; `out` receives
     sum(recv_counts) rows, grouped by source rank.  Row payloads of any width / dtype."""
@@ -145,7 +148,22 @@ def all_to_all_rows(out, inp, recv_counts, send_counts, group=None):
         dist.all_to_all_single(h_out, i.cpu().contiguous(), list(recv_counts), list(send_counts), group=group)
         o.copy_(h_out)
     else:
-        dist.all_to_all_single(o, i, list(recv_counts), list(send_counts), group=group)
+        # Messages of 2 GB and more come back half-copied from all_to_all_single on this stack (torch 2.10 / RCCL 2.26, seen with a
+        # one-rank group whose whole payload is a self-send: tests/test_gpu_dp.py pins it): beyond 1 GiB per peer the payload goes
+        # in column slices, each exchanged on its own.
+        row_bytes = (i[0].numel() if n_in else (o[0].numel() if n_out else 0)) * i.element_size()
+        worst = max([0] + [int(c) for c in send_counts] + [int(c) for c in recv_counts]) * row_bytes
+        parts = -(-worst // _A2A_MAX_BYTES) if worst else 1
+        if parts <= 1 or i.dim() != 2:
+            dist.all_to_all_single(o, i, list(recv_counts), list(send_counts), group=group)
+        else:
+            width = i.shape[1]
+            step = -(-width // parts)
+            for c0 in range(0, width, step):
+                c1 = min(c0 + step, width)
+                part = torch.empty((n_out, c1 - c0), dtype=o.dtype, device=o.device)
+                dist.all_to_all_single(part, i[:, c0:c1].contiguous(), list(recv_counts), list(send_counts), group=group)
+                o[:, c0:c1] = part
     return o
 
 

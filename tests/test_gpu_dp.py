@@ -482,3 +482,39 @@ def test_one_rank_rccl_group_runs_the_data_parallel_step(tmp_path, model_name, o
             np.testing.assert_array_equal(plain[k], rccl[k], err_msg=k)
         else:
             np.testing.assert_allclose(rccl[k], plain[k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+def _big_a2a_worker(rank, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from openkeonspark_amd import parallel
+    rows, D = 1_100_000, 512                                   # 2.25 GB of row payload
+    inp = (torch.arange(rows * D, device="cuda", dtype=torch.float32) % 1000003).view(rows, D)
+    raw = torch.zeros_like(inp)
+    dist.all_to_all_single(raw, inp, [rows], [rows])
+    torch.cuda.synchronize()
+    raw_bad = int((raw != inp).any(dim=1).sum())
+    del raw
+    out = torch.zeros_like(inp)
+    got = parallel.all_to_all_rows(out, inp, [rows], [rows])
+    torch.cuda.synchronize()
+    ours_bad = int((got != inp).any(dim=1).sum())
+    np.savez(os.path.join(out_dir, "a2a.npz"), raw_bad=raw_bad, ours_bad=ours_bad)
+    dist.destroy_process_group()
+
+
+def test_row_exchange_of_more_than_two_gigabytes_arrives_whole(tmp_path):
+    """`all_to_all_single` on this stack returns a 2 GB+ message half-copied (found when the table-sharded step was run at BASELINE
+    config #5's per-GPU batch on a one-rank group: loss 5.47 instead of 1.007).  parallel.all_to_all_rows slices such payloads; this
+    pins both the slicing and -- informationally -- whether the library still shows the fault."""
+    import torch.multiprocessing as mp
+    mp.start_processes(_big_a2a_worker, args=(29800 + os.getpid() % 1000, str(tmp_path)), nprocs=1, join=True, start_method="spawn")
+    z = np.load(str(tmp_path / "a2a.npz"))
+    from conftest import parity_report
+    parity_report("all_to_all_single_2GB_rows_corrupted_by_the_library", rows=int(z["raw_bad"]))
+    assert int(z["ours_bad"]) == 0

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--ent-exponent", type=float, default=0.8, help="Zipf exponent of entity popularity (0 = uniform)")
     ap.add_argument("--dense", action="store_true", help="dense count image instead of the sparse-row path")
+    ap.add_argument("--force-dp", action="store_true", help="one-rank RCCL group + Config.force_data_parallel: the table-sharded multi-GPU step, every exchange a copy")
     ap.add_argument("--model", default="TransE", help="TransE | TransH | TransD (the latter two: --dense = gradient tables + sweep, else row-wise SGD in place)")
     ap.add_argument("--opt", default="SGD", help="SGD | Adam (TF1 dense sweep, parity; implies --dense) | LazyAdam (touched rows only, NON-PARITY)")
     a = ap.parse_args()
@@ -30,6 +31,11 @@ def main():
     import torch
     import openkeonspark_amd as ok
     from openkeonspark_amd.synthetic import generate_triples
+    if a.force_dp:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     t0 = time.time()
     if a.ent_exponent == 0.0:   # uniform popularity: plain draws (the Zipf inverse-CDF search takes minutes at 500 M triples)
         rng = np.random.default_rng(5)
@@ -56,6 +62,9 @@ def main():
     del h, t, r
     t0 = time.time()
     con.set_model_and_session(getattr(ok, a.model))
+    if a.force_dp:
+        con.force_data_parallel = True
+        con.init_distributed()
     torch.cuda.synchronize()
     t_init = time.time() - t0
     for _ in range(a.warmup):
@@ -69,7 +78,7 @@ def main():
     B = con.batch_size
     print(json.dumps({"workload": "synthetic KG %dM entities / %dM triples %s dim=%d %s %d neg/pos, %s" % (
         a.entities // 1_000_000, a.triples // 1_000_000, a.model, a.dim, a.opt, a.neg,
-        "dense image / gradient tables + sweep" if (a.dense or a.opt == "Adam") else "sparse rows"),
+        ("dense image / gradient tables + sweep" if (a.dense or a.opt == "Adam") else "sparse rows") + (", table-sharded step on a one-rank RCCL group" if a.force_dp else "")),
         "ent_exponent": a.ent_exponent, "batch": B, "ms_per_step": 1e3 * dt / a.steps, "positives_per_s": B * a.steps / dt, "loss": float(loss.item()),
         "hbm_allocated_GB": torch.cuda.max_memory_allocated() / 1e9,
         "seconds": {"generate": round(t_gen, 1), "index": round(t_index, 1), "table_init": round(t_init, 1)}}))
