@@ -108,6 +108,7 @@ def _declare(L):
     L.kge_shard_record_ids.argtypes = [vp, i64, i64, vp, vp, vp]
     L.kge_shard_pack_records.argtypes = [vp, vp, i64, i64, vp, vp]
     L.kge_shard_relation_counts.argtypes = [vp, vp, i64, i64, i64, i64, i64, vp, vp]
+    L.kge_shard_scatter_count_rows.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, vp]
     L.kge_train_steps_persistent.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, i64, i64, i64, i64, i32, vp, f32, f32, f32, vp, vp]
     L.kge_persistent_aborted.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     L.kge_persistent_trace.argtypes = [vp, i64]

@@ -164,6 +164,18 @@ __global__ __launch_bounds__(256) void shard_rel_counts_kernel(const uint32_t *_
     }
 }
 
+// image[rows[i] - base, :] = counts[i, :] for the *n_rows_p compact rows (image zeroed by the caller; rows outside [base, base + R) skipped)
+__global__ __launch_bounds__(256) void shard_scatter_count_rows_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ counts,
+                                                                       const int32_t *__restrict__ n_rows_p, long long base, long long R, int D4,
+                                                                       int32_t *__restrict__ image) {
+    const long long total = (long long)n_rows_p[0] * D4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long u = i / D4, c = i - u * D4;
+        const long long r = (long long)rows[u] - base;
+        if (r >= 0 && r < R) reinterpret_cast<int4 *>(image)[r * D4 + c] = reinterpret_cast<const int4 *>(counts)[i];
+    }
+}
+
 unsigned blocks_for(long long n, int per_block = 256, long long cap = 16384) {
     long long b = (n + per_block - 1) / per_block;
     if (b > cap) b = cap;
@@ -260,6 +272,17 @@ int kge_shard_relation_counts(const uint32_t *d_rec, const int32_t *d_dst, INT n
     hipLaunchKernelGGL(shard_rel_counts_kernel, dim3(blocks_for(n_records, 4, 16384)), dim3(256), 0, (hipStream_t)stream, d_rec, d_dst,
                        (long long)n_records, (long long)cache_rows, (long long)rel_total, (int)dwords, (int)dim, d_counts);
     return hip_check(hipGetLastError(), "shard relation counts launch");
+}
+
+int kge_shard_scatter_count_rows(const int32_t *d_rows, const int32_t *d_row_counts, const int32_t *d_n_rows, INT max_rows, INT base,
+                                 INT rel_total, INT dim, int32_t *d_image, void *stream) {
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_shard_scatter_count_rows: no usable HIP device");
+    if (!d_rows || !d_row_counts || !d_n_rows || !d_image || max_rows < 0 || rel_total <= 0 || dim <= 0 || dim % 4)
+        return fail(KGE_ERR_BAD_ARG, "kge_shard_scatter_count_rows: bad arguments (dim % 4 == 0)");
+    if (max_rows == 0) return KGE_OK;
+    hipLaunchKernelGGL(shard_scatter_count_rows_kernel, dim3(blocks_for(max_rows * (dim / 4))), dim3(256), 0, (hipStream_t)stream, d_rows,
+                       d_row_counts, d_n_rows, (long long)base, (long long)rel_total, (int)(dim / 4), d_image);
+    return hip_check(hipGetLastError(), "shard scatter count rows launch");
 }
 
 }  // extern "C"
