@@ -39,7 +39,7 @@ def test_grow_table_appends_xavier_or_zero_rows():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("opt", ["SGD", "Adam"])
+@pytest.mark.parametrize("opt", ["SGD", "Adam", "LazyAdam"])   # LazyAdam: the opt-in non-parity touched-rows Adam (its moments and powers travel too)
 def test_checkpoint_resume_is_bit_identical(tmp_path, opt, monkeypatch):
     monkeypatch.setenv("KGE_COUNTS_MIN_RECORDS", "0")   # the exact count pipeline: reproducible bit for bit at any step size
     out = str(tmp_path / "run")
