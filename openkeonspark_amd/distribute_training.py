@@ -63,8 +63,9 @@ def parse_args(argv=None):
     p.add_argument("--test_head", type=int, default=0)
     p.add_argument("--work_threads", type=int, default=8, help="virtual sampler threads (Config.py:65 hard-codes 8)")
     p.add_argument("--seed", type=int, default=0, help="parameter initialisation seed")
-    p.add_argument("--sparse_rows", type=int, default=-1, help="1 / 0: force / forbid the sparse touched-row TransE path (default: automatic "
-                                                             "above 8 GB of tables); on N ranks its entity table is sharded by row range")
+    p.add_argument("--sparse_rows", type=int, default=-1, help="1 / 0: force / forbid the touched-rows-only update: TransE int8 records (SGD, or the opt-in non-parity "
+                                                             "--optimizer LazyAdam; on N ranks the entity table is sharded by row range), TransH / TransD float records "
+                                                             "added to the parameter rows in place (SGD, one process).  Default: automatic for large tables")
     return p.parse_args(argv)
 
 
