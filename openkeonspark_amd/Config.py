@@ -355,7 +355,8 @@ class Config(object):
         pair_path = getattr(self, "_desc", None) is not None and \
             bool(self.lib.kge_pair_path_active(ctypes.byref(self._desc), max(self._n_local, 1) if hasattr(self, "_n_local") else self.batch_size, n_neg))
         transr = getattr(self, "trainModel", None) is not None and self.trainModel.model_id == _lib.TRANSR
-        return bool(self.world_size > 1 or counts_path or pair_path or transr)
+        dense_one_gpu = not getattr(self, "sparse_rows", False) and not getattr(self, "sparse_inplace", False)
+        return bool(self.world_size > 1 or counts_path or pair_path or transr or dense_one_gpu)
 
     @property
     def _dp(self):
@@ -802,9 +803,10 @@ class Config(object):
             else:
                 self.apply_counts(denom)
         else:
-            # TransR on one GPU: the next batch's sampler rides in the relation-scatter launch of the step (a dozen to a hundred
-            # workgroups on 256 CUs), as it rides in the bucket scatter of the TransE path; other models keep the side stream
-            ride = batch_h is None and self.prefetch_sampling and not self._dp and self.trainModel.model_id == _lib.TRANSR
+            # one GPU: the next batch's sampler rides in a launch of the step that leaves most of the chip idle -- TransR's relation
+            # scatter, the record paths' bucket scatter, the atomic path's forward/backward kernel itself (a few hundred
+            # latency-bound workgroups at the reference's batch sizes); a path without such a launch runs it on its own afterwards
+            ride = batch_h is None and self.prefetch_sampling and not self._dp
             if ride:
                 self._attach_next_batch()
             try:

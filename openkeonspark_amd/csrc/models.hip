@@ -20,6 +20,7 @@
 // Gradients are ADDED into dense per-table accumulators (the deduplicated IndexedSlices sum that
 // TF1 forms before the optimizer) with hardware fp32 atomics.
 #include "models_dev.hpp"
+#include "sampler_dev.hpp"
 
 namespace kge {
 
@@ -657,6 +658,29 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
     return hip_check(hipGetLastError(), "transe emit launch");
 }
 
+// The atomic-path kernel with the NEXT batch's sampler riding in its launch (kge_sampling_attach): at the reference's batch
+// sizes this launch is a few hundred latency-bound workgroups on 256 CUs, and the sampler -- a pointer chase that depends on
+// nothing in the step -- took a quarter of the step as a launch of its own (config #1: 9.7 of 38 us).  Workgroups beyond
+// a.loss_blocks are the sampler's.
+template <int MODEL, int L, int C>
+__global__ __launch_bounds__(256) void fwdbwd_ride_kernel(FbArgs a, SamplerArgs ride, int n_ride) {
+    if ((int)blockIdx.x >= a.loss_blocks) {
+        __shared__ float bern_lds[kBernLds];
+        sample_block(ride, (long long)blockIdx.x - a.loss_blocks, n_ride, bern_lds);
+        return;
+    }
+    fwdbwd_body<MODEL, L, C, false>(a);
+}
+template <int MODEL, int L, int C>
+__global__ __launch_bounds__(256, 4) void fwdbwd_ride_kernel_occ4(FbArgs a, SamplerArgs ride, int n_ride) {   // (see fwdbwd_kernel_occ4)
+    if ((int)blockIdx.x >= a.loss_blocks) {
+        __shared__ float bern_lds[kBernLds];
+        sample_block(ride, (long long)blockIdx.x - a.loss_blocks, n_ride, bern_lds);
+        return;
+    }
+    fwdbwd_body<MODEL, L, C, false>(a);
+}
+
 template <int MODEL, int L, int C>
 static void launch_fb(const FbArgs &a, float *d_loss, hipStream_t stream) {
     constexpr int TEAMS = 256 / L;
@@ -666,6 +690,21 @@ static void launch_fb(const FbArgs &a, float *d_loss, hipStream_t stream) {
     FbArgs f = a;
     guard_loss_stream(stream);
     f.loss_out = d_loss; f.loss_ticket = engine().dev.loss_ticket;   // the last block writes the loss
+    if constexpr (MODEL != KGE_TRANSR) {     // (TransR's armed sampler has ridden in its relation scatter by now)
+        SamplerArgs ride = {};
+        unsigned n_ride = 0;
+        if (upload_jump_table() == KGE_OK && take_attached_sampler(ride, n_ride) && n_ride > 0) {
+            f.loss_blocks = (int)blocks;
+            if constexpr (MODEL != KGE_TRANSE && C <= 4) {
+                if (engine().fb_occ4) {
+                    hipLaunchKernelGGL((fwdbwd_ride_kernel_occ4<MODEL, L, C>), dim3((unsigned)blocks + n_ride), dim3(256), 0, stream, f, ride, (int)n_ride);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((fwdbwd_ride_kernel<MODEL, L, C>), dim3((unsigned)blocks + n_ride), dim3(256), 0, stream, f, ride, (int)n_ride);
+            return;
+        }
+    }
     if constexpr (MODEL != KGE_TRANSE && C <= 4) {
         if (engine().fb_occ4) { hipLaunchKernelGGL((fwdbwd_kernel_occ4<MODEL, L, C>), dim3((unsigned)blocks), dim3(256), 0, stream, f); return; }
     }

@@ -53,6 +53,10 @@ struct FbArgs {
     // data-parallel TransE count path: the loss also goes out as four 16-bit limbs of a 2^-32 fixed-point value, into the spare tail
     // slot of the int32 count image that the reduce-scatter sums (kge_loss_limbs_target; same encoding as kge_loss_to_limbs)
     int32_t *loss_limbs;
+    // a launch whose grid carries workgroups of ANOTHER job behind its own (the next batch's sampler riding along, models.hip
+    // fwdbwd_ride_kernel): the number of workgroups that are this kernel's -- what the loss ticket and the group loop count with
+    // instead of gridDim.x; 0 = the whole grid
+    int loss_blocks;
 };
 
 int ensure_loss_buffers();
@@ -65,6 +69,7 @@ template <int TEAMS>
 __device__ __forceinline__ void finish_loss(const FbArgs &a, float *red, float lsum, int lane, int team_in_block) {
     __shared__ float sh[256];
     __shared__ int is_last;
+    const unsigned nblk = a.loss_blocks ? (unsigned)a.loss_blocks : gridDim.x;   // this kernel's own workgroups
     if (lane == 0) red[team_in_block] = lsum;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -87,8 +92,8 @@ __device__ __forceinline__ void finish_loss(const FbArgs &a, float *red, float l
             // Two-level ticket: same-address memory-side atomics serialise at ~8 ns each, so thousands of blocks on ONE
             // counter cost more than the kernel they replace (measured +17 us on a 22 us kernel); 32 blocks share a
             // sub-counter (loss_ticket[1 + group]) and only the last of each group touches the master (loss_ticket[0]).
-            const unsigned group = blockIdx.x >> 5, n_groups = (gridDim.x + 31) >> 5;
-            const unsigned in_group = min(32u, gridDim.x - (group << 5));
+            const unsigned group = blockIdx.x >> 5, n_groups = (nblk + 31) >> 5;
+            const unsigned in_group = min(32u, nblk - (group << 5));
             if (__hip_atomic_fetch_add(a.loss_ticket + 1 + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_group - 1) {
                 __hip_atomic_store(a.loss_ticket + 1 + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 is_last = __hip_atomic_fetch_add(a.loss_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1 ? 1 : 0;
@@ -102,7 +107,7 @@ __device__ __forceinline__ void finish_loss(const FbArgs &a, float *red, float l
     if (!is_last) return;
     const unsigned *part = reinterpret_cast<const unsigned *>(a.loss_partials);
     float s = 0.f;   // same fixed order as loss_finalize_kernel
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+    for (int i = threadIdx.x; i < (int)nblk; i += 256)
         s += __uint_as_float(__hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     sh[threadIdx.x] = s;
     __syncthreads();
@@ -465,7 +470,8 @@ __device__ __forceinline__ void fwdbwd_body(const FbArgs &a) {
     const int team_in_block = threadIdx.x / L;
     float lsum = 0.f;
     const long long n_groups = a.group_list ? (long long)a.group_count[0] : a.n_pos;
-    for (long long gi = (long long)blockIdx.x * TEAMS + team_in_block; gi < n_groups; gi += (long long)gridDim.x * TEAMS) {
+    const long long own_blocks = a.loss_blocks ? a.loss_blocks : (long long)gridDim.x;
+    for (long long gi = (long long)blockIdx.x * TEAMS + team_in_block; gi < n_groups; gi += own_blocks * TEAMS) {
         const long long b = a.group_list ? (long long)a.group_list[gi] : gi;
         fwdbwd_group<MODEL, L, C, REC>(tm, a, b, lsum);
     }
