@@ -163,9 +163,8 @@ def gpu_config1(fb_dir, device, steps=2000):
         con.device = device
         con.set_in_path(fb_dir); con.set_work_threads(WORK_THREADS); con.set_bern(0); con.set_dimension(100); con.set_nbatches(0)
         con.set_ent_neg_rate(1); con.set_rel_neg_rate(0); con.set_margin(1.0); con.set_alpha(0.01); con.set_opt_method("SGD")
-        con.prefetch_sampling = False
         con.init()
-        con.set_model_and_session(TransE)
+        con.set_model_and_session(TransE)      # (defaults: the next batch's sampler rides in the forward/backward launch)
         assert con.batch_size == 2721
         if persistent and not con.persistent_supported():
             continue

@@ -504,8 +504,15 @@ class Config(object):
         self._refresh_pointers()
 
     def _stream(self):
+        """The current HIP stream of this Config's device, as the C ABI takes it.  Read through the raw accessor: building a
+        torch.cuda.Stream object per call (torch.cuda.current_stream()) was 60 % of the host time of a step at the reference's
+        batch sizes, where the host, not the GPU, set the step time (tools/host_bound_small.py)."""
         import torch
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if getattr(self, "_dev_index_of", None) != self.device:       # (callers may set con.device after construction)
+            d = torch.device(self.device)
+            self._dev_index = d.index if d.index is not None else torch.cuda.current_device()
+            self._dev_index_of = self.device
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(self._dev_index))
 
     def _ensure_dev_batch(self, stride):
         import torch
@@ -530,7 +537,6 @@ class Config(object):
         streams and the dataset only, never on the parameters, so batch i+1 is drawn while step i's
         reduction / gradient exchange / update run.  Same batches, same order, same bits."""
         import torch
-        main = torch.cuda.current_stream()
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream()
             self._slot = 0
@@ -540,8 +546,8 @@ class Config(object):
             dev, n_pos = self.sample_device(self._slot)
         else:
             dev, n_pos, ev = self._prefetched
-            if ev is not None:            # (None: drawn on this stream by a sampler that rode in the scatter launch)
-                main.wait_event(ev)
+            if ev is not None:            # (None: drawn on this stream by a sampler that rode in a launch of the step)
+                torch.cuda.current_stream().wait_event(ev)
         return dev, n_pos
 
     def _attach_next_batch(self):

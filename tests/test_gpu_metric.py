@@ -78,9 +78,12 @@ def test_trained_model_reaches_the_oracle_trained_metrics(graph):
                 # the two rankers count candidates scoring STRICTLY below the target (Test.h:60,170) on fp32 scores from two
                 # implementations (sums over the dimension in different orders): a differing count must come from a candidate whose
                 # score is within 2e-6 relative of the target's
+                # (several candidates can sit at such a near-tie at once -- seen: two, 1.5e-8 from the target -- so the counts may
+                # differ by as many as there are candidates inside that band, not just by one)
                 flips += 1
-                gap = np.abs(np.delete(fixed_scores, target) - fixed_scores[target]).min()
-                assert np.abs(got[:4] - want[:4]).max() <= 1 and gap <= 2e-6 * abs(fixed_scores[target]), (i, side, got, want, gap)
+                others = np.abs(np.delete(fixed_scores, target) - fixed_scores[target])
+                near = int((others <= 2e-6 * abs(fixed_scores[target])).sum())
+                assert 1 <= np.abs(got[:4] - want[:4]).max() <= near, (i, side, got, want, near, others.min())
     # (2) metric-level agreement of the two trainers, whole test set, both sides
     report = dict(graph=graph, steps=steps, test_triples=int(ev.testTotal), final_loss_engine=loss_g, final_loss_oracle=loss_o,
                   ranker_vectors_differing_by_one=flips, ranker_vectors_checked=2 * min(sample, ev.testTotal))
