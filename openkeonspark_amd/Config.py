@@ -512,7 +512,8 @@ class Config(object):
             d = torch.device(self.device)
             self._dev_index = d.index if d.index is not None else torch.cuda.current_device()
             self._dev_index_of = self.device
-        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(self._dev_index))
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)      # (a private accessor: fall back to the public object if it ever goes)
+        return ctypes.c_void_p(raw(self._dev_index) if raw is not None else torch.cuda.current_stream().cuda_stream)
 
     def _ensure_dev_batch(self, stride):
         import torch
