@@ -844,9 +844,11 @@ class Config(object):
         return self.batch_size * slots < int(getattr(self, "persistent_max_rows", 1 << 16))
 
     def persistent_preferred(self):
-        """Is the persistent launch the FASTER way to run this configuration?  Measured: TransE at its auto
-        batch 27.8 us/step against 35.2 as separate launches; TransH / TransD steps are bound by the fp32-atomic rate of their
-        gradient rows either way and the separate launches are slightly quicker (72 vs 77 us at config #3's batch)."""
+        """Is the persistent launch the FASTER way to run this configuration?  Measured (profiles/r03_a_other_configs.jsonl and the
+        bench line's config-#1 leg): TransE at its auto batch 26-27 us/step against 27-29 as separate launches (round 2: 27.8
+        against 35.2 -- the sampler now rides in the forward/backward launch and the host side of a step is cheaper); TransH /
+        TransD steps are bound by the fp32-atomic rate of their gradient rows either way and the separate launches are quicker
+        (66-70 vs 77-80 us at config #3's batch)."""
         return self.persistent_supported() and self.trainModel.model_id == _lib.TRANSE
 
     def train_steps(self, n_steps, persistent=None):
