@@ -174,7 +174,6 @@ class StreamRccl:
     four stream hand-offs per step, measured as ~45 us of idle GPU on a 0.28 ms step with a one-rank group.  Enqueued in order on
     one stream the hand-offs disappear.  The library is the librccl.so that torch itself loaded (no second RCCL in the process);
     the communicator is bootstrapped by broadcasting ncclUniqueId through the torch process group.  "nccl" backend only."""
-    _DT = None
 
     def __init__(self, group=None):
         import ctypes
