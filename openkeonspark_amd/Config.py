@@ -1011,17 +1011,17 @@ class Config(object):
         # 1. which entity rows does this slice touch, and who owns them
         _lib.check(L.kge_shard_requests(h.data_ptr(), t.data_ptr(), r.data_ptr(), n_pos, n_neg, bstride, b["req"].data_ptr(), st), L)
         _lib.check(L.kge_shard_count(b["req"].data_ptr(), M, chunk, W, b["counts"].data_ptr(), st), L)
-        send, recv = par.exchange_counts(b["counts"], pg)
+        send, recv, gmax = par.exchange_counts_max(b["counts"], pg)
         h_counts = (ctypes.c_int64 * W)(*send)
         _lib.check(L.kge_shard_scatter(b["req"].data_ptr(), M, chunk, W, h_counts, b["cursor"].data_ptr(), b["send_ids"].data_ptr(),
                                        b["slot_of"].data_ptr(), st), L)
         n_send, n_recv = sum(send), sum(recv)
         b = self._shard_buffers(M, n_recv, 0)
         # 2. ids out, rows back
-        par.all_to_all_rows(b["recv_ids"], b["send_ids"], recv, send, pg)
+        par.all_to_all_rows(b["recv_ids"], b["send_ids"], recv, send, pg, max_rows=gmax)
         _lib.check(L.kge_shard_gather_rows(self._tables[0].data_ptr(), b["recv_ids"].data_ptr(), n_recv, sh["lo"], chunk, D,
                                            b["rows_out"].data_ptr(), st), L)
-        par.all_to_all_rows(b["cache"], b["rows_out"], send, recv, pg)
+        par.all_to_all_rows(b["cache"], b["rows_out"], send, recv, pg, max_rows=gmax)
         # 3. the unchanged emit kernel over the fetched rows: the batch in terms of cache slots
         if self._dev_batch2 is None or self._dev_batch2.shape != dev_batch.shape:
             self._dev_batch2 = torch.zeros_like(dev_batch)
@@ -1053,15 +1053,15 @@ class Config(object):
         # 5. entity records to their owners
         _lib.check(L.kge_shard_record_ids(b["dst"].data_ptr(), M, n_send, b["send_ids"].data_ptr(), b["ids2"].data_ptr(), st), L)
         _lib.check(L.kge_shard_count(b["ids2"].data_ptr(), M, chunk, W, b["counts"].data_ptr(), st), L)
-        send2, recv2 = par.exchange_counts(b["counts"], pg)
+        send2, recv2, gmax2 = par.exchange_counts_max(b["counts"], pg)
         h_counts2 = (ctypes.c_int64 * W)(*send2)
         _lib.check(L.kge_shard_scatter(b["ids2"].data_ptr(), M, chunk, W, h_counts2, b["cursor"].data_ptr(), b["send_rows2"].data_ptr(),
                                        b["slot_of2"].data_ptr(), st), L)
         _lib.check(L.kge_shard_pack_records(b["rec"].data_ptr(), b["slot_of2"].data_ptr(), M, dw, b["send_rec"].data_ptr(), st), L)
         n_recv2 = sum(recv2)
         b = self._shard_buffers(M, n_recv, n_recv2)
-        par.all_to_all_rows(b["recv_rows2"], b["send_rows2"], recv2, send2, pg)
-        par.all_to_all_rows(b["recv_rec"], b["send_rec"], recv2, send2, pg)
+        par.all_to_all_rows(b["recv_rows2"], b["send_rows2"], recv2, send2, pg, max_rows=gmax2)
+        par.all_to_all_rows(b["recv_rec"], b["send_rec"], recv2, send2, pg, max_rows=gmax2)
         # 6. owner: sort by row, segmented sum, SGD on the touched rows of the shard
         if n_recv2 > 0:
             b["recv_rows2"][:n_recv2].sub_(sh["lo"])

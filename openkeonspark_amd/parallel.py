@@ -115,28 +115,36 @@ def all_gather_chunks(out, inp, group=None, async_op=False):
     return work if async_op else None
 
 
-def exchange_counts(send_counts, group=None):
-    """send_counts: int32 device tensor [world] (how many rows this rank sends to each peer).  Returns the two HOST lists
-    (send, recv): the one synchronisation point of a variable-size exchange."""
+def exchange_counts_max(send_counts, group=None):
+    """send_counts: int32 tensor [world] (how many rows this rank sends to each peer).  Returns the two HOST lists (send, recv)
+    -- the one synchronisation point of a variable-size exchange -- and the LARGEST per-peer row count anywhere in the group
+    (every rank's own maximum travels in the same all-to-all as a second column): the number all ranks must agree on before
+    they decide how to cut an oversized payload (all_to_all_rows)."""
     import torch
     import torch.distributed as dist
-    recv = torch.empty_like(send_counts)
-    if _host_staged(send_counts, group):
-        h = send_counts.cpu()
-        h_recv = torch.empty_like(h)
-        dist.all_to_all_single(h_recv, h, group=group)
-        return h.tolist(), h_recv.tolist()
-    dist.all_to_all_single(recv, send_counts, group=group)
-    both = torch.stack([send_counts, recv]).cpu()
-    return both[0].tolist(), both[1].tolist()
+    staged = _host_staged(send_counts, group)
+    src = send_counts.cpu() if staged else send_counts
+    pair = torch.stack([src, src.max().expand_as(src)], dim=1).contiguous()      # [world, 2]: (rows for peer p, this rank's maximum)
+    got = torch.empty_like(pair)
+    dist.all_to_all_single(got, pair, group=group)
+    h_send, h_got = src.cpu().tolist(), got.cpu()
+    return h_send, h_got[:, 0].tolist(), int(h_got[:, 1].max())
+
+
+def exchange_counts(send_counts, group=None):
+    """(send, recv) of exchange_counts_max."""
+    send, recv, _ = exchange_counts_max(send_counts, group)
+    return send, recv
 
 
 _A2A_MAX_BYTES = 1 << 30      # per-peer message size above which all_to_all_rows slices the payload (see there)
 
 
-def all_to_all_rows(out, inp, recv_counts, send_counts, group=None):
+def all_to_all_rows(out, inp, recv_counts, send_counts, group=None, max_rows=None):
     """Variable-size all-to-all along dim 0: rows [sum(send[:p]), sum(send[:p+1])) of `inp` go to peer p; `out` receives
-    sum(recv_counts) rows, grouped by source rank.  Row payloads of any width / dtype."""
+    sum(recv_counts) rows, grouped by source rank.  Row payloads of any width / dtype.  max_rows: the largest per-peer row count in
+    the whole group (exchange_counts_max) -- with more than one rank every rank must pass it, so that all of them cut an oversized
+    payload into the same number of slices."""
     import torch
     import torch.distributed as dist
     n_out, n_in = int(sum(recv_counts)), int(sum(send_counts))
@@ -151,8 +159,8 @@ def all_to_all_rows(out, inp, recv_counts, send_counts, group=None):
         # Messages of 2 GB and more come back half-copied from all_to_all_single on this stack (torch 2.10 / RCCL 2.26, seen with a
         # one-rank group whose whole payload is a self-send: tests/test_gpu_dp.py pins it): beyond 1 GiB per peer the payload goes
         # in column slices, each exchanged on its own.
-        row_bytes = (i[0].numel() if n_in else (o[0].numel() if n_out else 0)) * i.element_size()
-        worst = max([0] + [int(c) for c in send_counts] + [int(c) for c in recv_counts]) * row_bytes
+        row_bytes = (inp[0].numel() if inp.shape[0] else (out[0].numel() if out.shape[0] else 0)) * inp.element_size()
+        worst = (int(max_rows) if max_rows is not None else max([0] + [int(c) for c in send_counts] + [int(c) for c in recv_counts])) * row_bytes
         parts = -(-worst // _A2A_MAX_BYTES) if worst else 1
         if parts <= 1 or i.dim() != 2:
             dist.all_to_all_single(o, i, list(recv_counts), list(send_counts), group=group)

@@ -85,13 +85,25 @@ def _collectives_worker(rank, world, port, out_dir):
     assert torch.equal(flat, torch.cat([torch.arange(chunk, dtype=torch.float32) + 100 * g for g in range(world)]))
     # variable-size all-to-all of rows (ragged, including empty sends): rank r sends (r + p) % 3 rows to peer p
     send = [(rank + p) % 3 for p in range(world)]
-    s_counts, r_counts = par.exchange_counts(torch.tensor(send, dtype=torch.int32))
+    s_counts, r_counts, g_max = par.exchange_counts_max(torch.tensor(send, dtype=torch.int32))
     assert s_counts == send and r_counts == [(p + rank) % 3 for p in range(world)]
+    assert g_max == max((r + p) % 3 for r in range(world) for p in range(world))          # the same number on every rank
     rows = torch.tensor([[rank, p, i] for p in range(world) for i in range(send[p])], dtype=torch.int32).reshape(-1, 3)
     out = torch.full((sum(r_counts) + 2, 3), -7, dtype=torch.int32)
     got = par.all_to_all_rows(out, rows, r_counts, s_counts)
     want = torch.tensor([[p, rank, i] for p in range(world) for i in range(r_counts[p])], dtype=torch.int32).reshape(-1, 3)
     assert torch.equal(got, want) and int(out[sum(r_counts):].max()) == -7
+    # the same exchange with the per-peer message limit forced below one row block: the payload goes in column slices
+    # (all_to_all_rows' guard against the 2 GB fault of all_to_all_single, tests/test_gpu_dp.py) and must arrive identical
+    wide = torch.stack([rows[:, 0] * 1000 + rows[:, 1] * 10 + rows[:, 2] + c for c in range(7)], dim=1).to(torch.float32).reshape(-1, 7)
+    out_w = torch.full((sum(r_counts) + 1, 7), -7.0)
+    limit, par._A2A_MAX_BYTES = par._A2A_MAX_BYTES, 8
+    try:
+        got_w = par.all_to_all_rows(out_w, wide, r_counts, s_counts, max_rows=g_max)
+    finally:
+        par._A2A_MAX_BYTES = limit
+    want_w = torch.stack([want[:, 0] * 1000 + want[:, 1] * 10 + want[:, 2] + c for c in range(7)], dim=1).to(torch.float32).reshape(-1, 7)
+    assert torch.equal(got_w, want_w) and float(out_w[sum(r_counts):].max()) == -7.0
     assert par.chunk_size(10, 4) == 3 and par.chunk_size(10, 4, 4) == 4 and par.chunk_size(8, 4, 1) == 2
     open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     dist.destroy_process_group()
