@@ -178,6 +178,26 @@ def gpu_config1(fb_dir, device, steps=2000):
     return out
 
 
+def exchange_rehearsal(steps=100, warmup=20, timeout=240):
+    """The same workload once more through the data-parallel exchange, as far as one GPU allows: a CHILD process runs this
+    script on a one-rank RCCL group with Config.force_data_parallel (every collective of the step is issued; with one rank each
+    is a copy).  Reported beside the headline so that the N = 1 line already shows what the exchange machinery costs before any
+    byte crosses xGMI; not part of `value`.  Any failure is reported, never raised: it must not take the headline down."""
+    import subprocess
+    env = dict(os.environ, KGE_BENCH_FORCE_DIST="1", KGE_BENCH_FORCE_DP="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29650 + os.getpid() % 300), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline"],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout, check=False)
+        line = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        return {"what": "one-rank RCCL group, force_data_parallel: reduce-scatter / owned-share Adam / all-gather issued every step",
+                "ms_per_step": d["ms_per_step"], "value": d["value"], "backend": d["backend"], "rccl_ranks": d["rccl_ranks"],
+                "collective_stream": d.get("collective_stream"), "steps": d["steps"], "warmup": d["warmup"]}
+    except Exception as exc:      # noqa: BLE001 -- reported in the line instead
+        return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+
+
 def adam_step_bytes(ent_total, rel_total, dim):
     """TF1 'sparse' Adam is a dense sweep: every element of p, m, v is read and written each step
     (24 B) and the summed gradient image is read and re-zeroed (8 B)."""
@@ -392,6 +412,8 @@ def main():
                 os.close(saved_fd)
                 os.close(devnull_fd)
             out["cpu_baseline_config1"] = c1
+            if not use_dist:
+                out["exchange_rehearsal"] = exchange_rehearsal()
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
