@@ -14,7 +14,10 @@ inputs resident in HBM.  N GPUs = N processes, rank g owns the virtual sampler t
 chunk of the tables and the updated chunks are all-gathered.  Per-GPU batch is held at ~34 014 positives
 (nbatches = 8/N), so scaling is weak.
 
-python bench.py --gpus N --steps K --warmup W      (torchrun-launched for N > 1)
+python bench.py --gpus N --steps K --warmup W
+N > 1 from a bare shell: this process starts the N ranks itself (`python -m torch.distributed.run`, one rank per GPU, RCCL over
+xGMI) BEFORE anything touches a GPU, relays rank 0's JSON line and exits with the job's status -- what the reference's launcher
+does with TFCluster.run (main_spark.py:340).  Under an external torchrun (WORLD_SIZE set) it is one of the ranks.
 """
 import argparse
 import json
@@ -198,6 +201,40 @@ def exchange_rehearsal(steps=100, warmup=20, timeout=240):
         return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
 
 
+def launch_ranks(n, argv):
+    """Start `n` ranks of this script on this node and relay rank 0's line.  Runs in a process that has not initialised the GPU
+    (no HIP call, no torch.cuda call before this point), starts the ranks as CHILD processes and returns their status: nothing is
+    exec'ed over a process that holds a device."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:                       # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this stack
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=sys.stderr)
+    line = None
+    for raw in proc.stdout:                              # only rank 0's JSON line goes to our stdout
+        text = raw.decode(errors="replace").rstrip("\n")
+        if text.startswith("{"):
+            line = text
+        elif text:
+            print(text, file=sys.stderr)
+    rc = proc.wait()
+    if rc != 0:
+        print("bench.py: the %d-rank job failed (exit status %d)" % (n, rc), file=sys.stderr)
+        return rc if rc > 0 else 1
+    if line is None:
+        print("bench.py: the %d-rank job printed no result line" % n, file=sys.stderr)
+        return 1
+    print(line)
+    sys.stdout.flush()
+    return 0
+
+
 def adam_step_bytes(ent_total, rel_total, dim):
     """TF1 'sparse' Adam is a dense sweep: every element of p, m, v is read and written each step
     (24 B) and the summed gradient image is read and re-zeroed (8 B)."""
@@ -220,6 +257,11 @@ def main():
                          "bit-identical batches).  auto = the Config default")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if PER_GPU_NBATCHES % args.gpus:
+            raise SystemExit("--gpus must divide %d" % PER_GPU_NBATCHES)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))     # (before any GPU call in this process)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -228,9 +270,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a torchrun launch with that many ranks" % args.gpus)
-        args.gpus = world
+        args.gpus = world       # an external launcher's world size wins over the flag
     if os.environ.get("KGE_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0   # rehearsal of the N-rank code path on a one-GPU box (with KGE_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
@@ -299,7 +339,9 @@ def main():
     n_local = con._n_local
 
     def sync():
+        torch.cuda.synchronize()      # (drained before the process group's barrier: the step's collectives may be on the engine's own communicator)
         if use_dist:
+            con.comm_fence("pg")
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -317,6 +359,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if use_dist:
+        con.comm_fence("pg")
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())

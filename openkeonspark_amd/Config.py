@@ -655,6 +655,7 @@ class Config(object):
         ride = flat_img.numel() >= 4 and (not counts or self.hidden_size >= 4)
         last = self.rank == W - 1
         nat = self._stream_rccl() if (K == 1 and ride) else None
+        self.comm_fence("nat" if nat is not None else "pg")
         if nat is not None:
             # one piece (tables below 64 MB): the two collectives go onto the engine's own stream, in order with its kernels
             # (parallel.StreamRccl) -- no process-group stream, no event hand-offs
@@ -708,23 +709,57 @@ class Config(object):
                 w.wait()
         # (ride: self._loss IS the tail slot of the parameter buffer -- the all-gather has just delivered the global loss into it)
 
+    def comm_fence(self, kind):
+        """Two RCCL communicators live in a data-parallel process: torch's process group ("pg": the sharded step, optimizer-state
+        gathers, evaluation reductions, the caller's own barriers) and the engine's own (parallel.StreamRccl, "nat": the dense
+        step's reduce-scatter / all-gather on the engine's stream).  Collectives of two communicators must never be in flight
+        together on a device: each spins on its peers, and two ranks that get them scheduled in opposite order wait on each other
+        for ever.  The rule enforced here: every collective is issued through ONE communicator per step path, and whenever the
+        communicator CHANGES (first step after a checkpoint gather, an evaluation, ...) the device is drained first -- every
+        collective this rank has enqueued so far has then completed, so its peers have all entered it, before a collective of
+        the other communicator is enqueued.  Every rank runs the same program, so all ranks fence at the same points.  Call it with
+        "pg" before using torch.distributed collectives of your own between training steps."""
+        last = getattr(self, "_last_comm", None)
+        if last is not None and last != kind:
+            import torch
+            torch.cuda.synchronize(self.device)
+        self._last_comm = kind
+
     def _stream_rccl(self):
         """The communicator for collectives on the engine's stream (parallel.StreamRccl): "nccl" backend, `stream_rccl` not switched
-        off.  Created on first use -- collectively: every rank reaches the first data-parallel step together."""
+        off (KGE_STREAM_RCCL=0 switches it off from the environment).  Created on first use -- collectively: every rank reaches the
+        first data-parallel step together -- and PROBED before it is trusted: a reduce-scatter and an all-gather of known values
+        through it must give the known sums on every rank, else (or on any error) all ranks fall back to the process group."""
         if getattr(self, "_nat_rccl", None) is None:
             import torch.distributed as dist
-            want = getattr(self, "stream_rccl", True) and dist.is_initialized() and dist.get_backend(self._pg) == "nccl"
+            want = getattr(self, "stream_rccl", os.environ.get("KGE_STREAM_RCCL", "1") != "0") and dist.is_initialized() and \
+                dist.get_backend(self._pg) == "nccl"
             nat = False
             if want:
                 import sys
                 import torch
                 from .parallel import StreamRccl
+                self.comm_fence("pg")
+                good = 0
                 try:
                     nat = StreamRccl(self._pg)
+                    torch.cuda.synchronize(self.device)
+                    W, g, st = nat.world, nat.rank, self._stream()
+                    src = torch.arange(4 * W, dtype=torch.int32, device=self.device) + g          # rank g contributes i + g
+                    own = torch.empty(4, dtype=torch.int32, device=self.device)
+                    nat.reduce_scatter_sum(own, src, st)
+                    full = torch.empty(4 * W, dtype=torch.int32, device=self.device)
+                    full[4 * g:4 * g + 4] = own
+                    nat.all_gather_chunks(full, full[4 * g:4 * g + 4], st)
+                    torch.cuda.synchronize(self.device)
+                    want_full = W * torch.arange(4 * W, dtype=torch.int32) + W * (W - 1) // 2      # sum_g (i + g)
+                    good = int(torch.equal(full.cpu(), want_full))
+                    if not good:
+                        print("StreamRccl probe gave wrong sums: collectives stay on the process group's stream", file=sys.stderr)
                 except Exception as exc:       # still RCCL either way: the process-group path is the documented alternative
                     print("StreamRccl unavailable (%s): collectives stay on the process group's stream" % exc, file=sys.stderr)
                 # every rank must take the same path (a rank on the other communicator would wait for ever): agree on the minimum
-                ok = torch.tensor([1 if nat else 0], dtype=torch.int32, device=self.device)
+                ok = torch.tensor([good], dtype=torch.int32, device=self.device)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self._pg)
                 if int(ok.item()) == 0:
                     if nat:
@@ -738,6 +773,7 @@ class Config(object):
         (checkpoints)."""
         if self._dp and self._adam and not self.sparse_rows and not getattr(self, "_opt_state_synced", True):
             from .parallel import all_gather_chunks
+            self.comm_fence("pg")
             for (slo, shi), (lo, hi) in zip(self._piece_seg, self._piece_own):
                 all_gather_chunks(self._flat_m[slo:shi], self._flat_m[lo:hi], self._pg)
                 all_gather_chunks(self._flat_v[slo:shi], self._flat_v[lo:hi], self._pg)
@@ -756,7 +792,7 @@ class Config(object):
             dev, n_pos = self._next_sampled_batch() if self.prefetch_sampling else self.sample_device()
             stride = max(self._n_local, 1)
         else:
-            if self.world_size != 1:
+            if self._dp:      # (also a one-rank group under force_data_parallel: the sharded step has no check for hand-made negatives)
                 raise KgeError("feeding a host batch is single-process only")
             host = np.stack([np.asarray(batch_h), np.asarray(batch_t), np.asarray(batch_r)]).astype(np.int32)
             self._check_ids(host)
@@ -1000,6 +1036,7 @@ class Config(object):
         import torch
         from . import parallel as par
         L, st, W, D, pg = self.lib, self._stream(), self.world_size, self.hidden_size, self._pg
+        self.comm_fence("pg")
         n_neg = self.negative_ent + self.negative_rel
         sh = self._shard
         chunk = sh["chunk"]
@@ -1279,6 +1316,7 @@ class Config(object):
         keys = sorted(sums)
         vec = torch.tensor([sums[k] for k in keys], dtype=torch.float64)
         if self.world_size > 1:
+            self.comm_fence("pg")
             if dist.get_backend(self._pg) == "nccl":
                 vec = vec.to(self.device)
             dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self._pg)
@@ -1312,6 +1350,7 @@ class Config(object):
             if self._sharded(var_name):   # collective: every rank must call it (the shards are gathered; small tables only)
                 import torch
                 from .parallel import all_gather_chunks
+                self.comm_fence("pg")
                 full = torch.empty((self._shard["chunk"] * self.world_size, t.shape[1]), dtype=t.dtype, device=t.device)
                 all_gather_chunks(full.view(-1), t.reshape(-1), self._pg)
                 return full[:self.entTotal].cpu().numpy()

@@ -176,6 +176,7 @@ def save_checkpoint(con, output_path, max_to_keep=10, write=True):
         _atomic_savez(base + ".shard%dof%d.npz" % (con.rank, con.world_size), rows=rows, lo=np.int64(sh["lo"]), hi=np.int64(sh["hi"]),
                       ent_total=np.int64(con.entTotal))
         import torch.distributed as dist
+        con.comm_fence("pg")
         dist.barrier(group=getattr(con, "_pg", None))      # all shard files of this step exist before anything points at them
     if not write:
         return None
@@ -413,6 +414,7 @@ def main_fun(argv):
                 f.write(str(time.time() - t0))
     if distributed:
         import torch.distributed as dist
+        con.comm_fence("pg")
         dist.barrier()
         if own_group:
             dist.destroy_process_group()

@@ -518,3 +518,27 @@ def test_row_exchange_of_more_than_two_gigabytes_arrives_whole(tmp_path):
     from conftest import parity_report
     parity_report("all_to_all_single_2GB_rows_corrupted_by_the_library", rows=int(z["raw_bad"]))
     assert int(z["ours_bad"]) == 0
+
+
+def test_bench_starts_its_own_ranks_from_a_bare_shell():
+    """`python3 bench.py --gpus 2 ...` from an environment with no launcher variables: bench.py itself starts the two ranks
+    (torch.distributed.run children, before anything in the parent touches the GPU), the ranks run the data-parallel step, and
+    the parent relays rank 0's single JSON line and exits 0.  On this one-GPU box the ranks share device 0 and use gloo
+    (KGE_BENCH_BACKEND / KGE_BENCH_SINGLE_DEVICE); the driver's 8-GPU run takes the same path with RCCL.  Replaces what the
+    reference's launcher does with TFCluster.run (/root/reference/main_spark.py:340)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK", "TORCHELASTIC_RUN_ID")}
+    env.update(KGE_BENCH_BACKEND="gloo", KGE_BENCH_SINGLE_DEVICE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                       # ONE line on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["rccl_ranks"] == 2
+    assert d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"]
+    assert np.isfinite(d["config"]["final_loss"]) and 0.0 < d["config"]["final_loss"] < 2.0
+    assert d["value"] > 0 and "roofline" in d

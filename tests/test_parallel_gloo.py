@@ -115,3 +115,21 @@ def test_exchange_helpers_on_gloo(tmp_path, world):
     port = 31500 + os.getpid() % 2000 + world
     mp.start_processes(_collectives_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
     assert all(os.path.exists(str(tmp_path / ("ok%d" % r))) for r in range(world))
+
+
+def test_bench_self_launch_reports_a_failing_rank(tmp_path):
+    """bench.py --gpus 2 from a bare shell starts its ranks itself (bench.launch_ranks; the reference's launcher:
+    /root/reference/main_spark.py:340).  Without a GPU every rank fails at its first device call: the parent must exit non-zero
+    and print no result line -- a failed N-rank job never looks like a measurement."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check (on a GPU box tests/test_gpu_dp.py runs the real thing)")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    # --gpus must divide the 8 virtual sampler threads: refused before anything is started
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode != 0 and b"must divide" in p.stderr
