@@ -291,7 +291,7 @@ def test_config2_fb15k237_transe_adam_n25_bench_size(fb_dir):
                   grad_relerr_fully_checked_rows=tot["grad"], rows_excused=tot["rows_excused"], rows_in_kink_set=tot["rows_in_kink_set"],
                   rows_fully_checked=tot["rows_fully_checked"], rows_excused_needing_a_switch_point=tot["rows_excused_needing_a_switch_point"],
                   worst_excused_diff_over_its_radius=tot["worst_excused_over_radius"],
-                  worst_oracle_fp32_error_on_excused_rows=tot["worst_oracle_fp32_error_on_excused_rows"],
+                  worst_oracle_minus_fp64_on_excused_rows_incl_its_own_switch_choices=tot["worst_oracle_fp32_error_on_excused_rows"],
                   worst_engine_error_vs_fp64_beyond_radius_on_excused_rows=tot["worst_engine_error_vs_fp64_on_excused_rows"],
                   elements_of_e_within_tol_of_zero=tot["kink_elems"], hinges_within_tie_tol=tot["tie_hinges"], kink_tol=KINK_TOL, tie_tol=TIE_TOL,
                   adam_elements_beyond_1e3_of_a_step_all_explained=tot["amplified"], worst_in_steps=tot["worst_steps"],
