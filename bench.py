@@ -249,9 +249,6 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-dtype", choices=["fp32", "bf16"], default="fp32",
-                    help="bf16: the NON-PARITY fast mode (rows gathered from bf16 shadows of the fp32 tables); a second, separately "
-                         "labelled line -- the fp32 default stays the headline")
     ap.add_argument("--prefetch-sampling", choices=["auto", "on", "off"], default="auto",
                     help="batch i+1 sampled on a side stream behind the emit kernel of step i (Config.prefetch_sampling; "
                          "bit-identical batches).  auto = the Config default")
@@ -319,7 +316,6 @@ def main():
     con.set_margin(1.0)
     con.set_alpha(0.001)
     con.set_opt_method("Adam")
-    con.gather_dtype = args.gather_dtype
     if args.prefetch_sampling != "auto":
         con.prefetch_sampling = args.prefetch_sampling == "on"
     con.init()
@@ -392,15 +388,14 @@ def main():
     _l.check(con.lib.kge_kernel_ms_mean(b"transe_emit", ctypes.byref(ms), ctypes.byref(timed)), con.lib)
     kern_ms = float(ms.value)
     n_pos = n_local
-    bf16 = args.gather_dtype == "bf16"
-    alg_bytes = algorithmic_bytes_per_positive(NEG, DIM, elem=2 if bf16 else 4) * n_pos
+    alg_bytes = algorithmic_bytes_per_positive(NEG, DIM) * n_pos
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic, traffic_note = None, None
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr_path):
         try:
             tr = json.load(open(tr_path))
-            traffic = None if bf16 else tr.get("emit_hbm_bytes_per_launch")     # measured on the fp32 kernel
+            traffic = tr.get("emit_hbm_bytes_per_launch")
             traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at commit %s (%s)" % (
                 tr.get("measured_at_commit", "?"), tr.get("source", "profiles/"))
         except Exception:
@@ -418,16 +413,16 @@ def main():
             "rccl_ranks": rccl_ranks, "collective_stream": collective_stream, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 row gathers, f32 arithmetic / master tables / Adam slots (NON-PARITY fast mode)" if bf16 else "f32",
+            "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "FB15k-237-shaped synthetic KG (E=14541,R=237,272115 triples), TransE dim=200, "
-                                   "TF1-semantics Adam, 25 neg/pos bern, margin 1.0 (BASELINE configs[1], %s)"
-                                   % ("bf16 storage for the gathers, as configs[1] is written; not the parity mode" if bf16 else "fp32"),
+                                   "TF1-semantics Adam, 25 neg/pos bern, margin 1.0 (BASELINE configs[1] in fp32, the reference's "
+                                   "precision: TransE.py:21-22)",
                        "global_batch": B, "per_gpu_batch": n_local, "neg_per_pos": NEG, "dim": DIM,
                        "optimizer": "Adam(dense, TF1 parity)", "gradient_path": "int8 sign-count records (exact)",
                        "work_threads": WORK_THREADS,
                        "parallelism": "dp%d" % world, "final_loss": loss},
-            "roofline": {"bound": "hbm", "kernel": "kge::transe_emit_vec_kernel<64,1,4,1,true%s>" % (",true" if bf16 else ""),
+            "roofline": {"bound": "hbm", "kernel": "kge::transe_emit_vec_kernel<64,1,4,1,true>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note, "kernel_ms": kern_ms,
                          "kernel_launches_timed": int(timed.value), "kernel_launches_timed_inside_region": min(in_region, int(timed.value)),

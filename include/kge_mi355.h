@@ -322,14 +322,6 @@ int kge_transe_apply_counts_range(const kge_model_desc *m, float *const d_p[2], 
                                   int32_t *d_counts_chunk, float *const d_resid[2], INT row_lo, INT row_hi, INT denom, int32_t adam,
                                   float lr, float beta1, float beta2, float eps, void *stream);
 
-/* NON-PARITY fast mode (BASELINE configs[1] names bf16 storage; the reference itself is fp32, TransE.py:21-22): register bf16
- * SHADOWS of the two TransE tables.  The fp32 tables stay the master copy the optimizer updates (and checkpoints hold); the
- * shadows are refreshed here and then kept equal to the rounded master rows by kge_transe_apply_counts_*; the vectorised emit
- * kernel of kge_transe_forward_counts gathers from them (8 B per lane instead of 16, half the gather bytes) whenever it is
- * called with exactly these master tables.  d_ent16 = d_rel16 = NULL unregisters.  Call again after writing the tables directly. */
-int kge_transe_set_bf16_shadow(const kge_model_desc *m, const float *d_ent, const float *d_rel, uint16_t *d_ent16, uint16_t *d_rel16,
-                               void *stream);
-
 /* ---- TransE sign-count path, stage level: for tables too large for a dense count image and for the
  * multi-GPU exchange, where the int8 records (8x smaller than fp32 gradient rows) are the wire format ----
  *   kge_transe_record_dwords : dwords per record for this embedding width

@@ -321,20 +321,7 @@ class Config(object):
         if self.use_counts and not self.sparse_rows:
             self._counts = torch.zeros((self.entTotal + self.relTotal, self.hidden_size), dtype=torch.int32,
                                        device=self.device)
-        # NON-PARITY fast mode (BASELINE configs[1] names bf16 storage; the reference is fp32, TransE.py:21-22): the emit kernel
-        # gathers rows from bf16 shadows of the tables (half the gather bytes); arithmetic, the master tables, Adam's m / v and
-        # the checkpoints stay fp32.  Off unless asked for: con.gather_dtype = "bf16".
-        self._shadow = None
-        self.gather_dtype = getattr(self, "gather_dtype", "fp32")
-        if self.gather_dtype not in ("fp32", "bf16"):
-            raise KgeError("gather_dtype must be 'fp32' or 'bf16'")
-        if self.gather_dtype == "bf16":
-            if not (self.use_counts and not self.sparse_rows and self.hidden_size % 4 == 0):
-                raise KgeError("gather_dtype='bf16' needs TransE on the dense sign-count path with a width that is a multiple of 4")
-            self.counts_min_records = 0        # every step takes the count pipeline (the one that keeps the shadows current)
         self._setup_partition()
-        if self.gather_dtype == "bf16":
-            self._refresh_shadow()
 
     # --- data-parallel partition: rank g owns virtual threads [g*W/G, (g+1)*W/G) ---
     def init_distributed(self, process_group=None):
@@ -382,17 +369,6 @@ class Config(object):
             else:
                 self._setup_flat_buffers()
             self._dist_ready = self.world_size
-
-    def _refresh_shadow(self):
-        """(Re)build the bf16 shadows from the fp32 master tables and register them with the engine: after the tables were
-        written from outside the optimizer (set_parameters, restore, the data-parallel all-gather of the updated chunks)."""
-        import torch
-        if self.gather_dtype != "bf16":
-            return
-        if self._shadow is None:
-            self._shadow = [torch.empty(self._tables[i].shape, dtype=torch.bfloat16, device=self._tables[i].device) for i in (0, 1)]
-        _lib.check(self.lib.kge_transe_set_bf16_shadow(ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(),
-                                                       self._shadow[0].data_ptr(), self._shadow[1].data_ptr(), self._stream()), self.lib)
 
     def _refresh_pointers(self):
         self.lib.kge_set_option(b"tables_changed", 1)
@@ -475,8 +451,6 @@ class Config(object):
             self._own_rows_len = own_r
         self._opt_state_synced = True
         self._refresh_pointers()
-        if getattr(self, "gather_dtype", "fp32") == "bf16":
-            self._refresh_shadow()        # the master tables moved into the flat buffer
 
     def _setup_shards(self):
         """Table-sharded sparse mode (config #5 on N GPUs): rank g keeps the entity rows [g*chunk, (g+1)*chunk) only; the
@@ -842,7 +816,6 @@ class Config(object):
                 # int32 SUM is exact: rank g receives the summed counts of ITS rows, updates them, and the updated rows go round
                 self._dp_exchange(self._counts, self._counts_own, lambda k: self.apply_counts(denom, own=True, piece=k), counts=True)
                 self.tables_changed()
-                self._refresh_shadow()
             else:
                 self.apply_counts(denom)
         else:
@@ -1389,8 +1362,6 @@ class Config(object):
             else:
                 dst.copy_(src.reshape(dst.shape))
             self.tables_changed()
-            if getattr(self, "_shadow", None) is not None:
-                self._refresh_shadow()
 
     def set_parameters(self, lists):
         for i in lists:

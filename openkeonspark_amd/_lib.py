@@ -98,7 +98,6 @@ def _declare(L):
     L.kge_transe_apply_rows_adam_lazy.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, f32, f32, f32, vp]
     L.kge_transe_reduce_apply_records_sgd.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, i64, vp, vp, vp, vp, vp, i64, f32, vp]
     L.kge_transe_apply_counts_range.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i64, i64, i32, f32, f32, f32, f32, vp]
-    L.kge_transe_set_bf16_shadow.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp]
     # table-sharded sparse path (csrc/shard.hip)
     L.kge_shard_requests.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp]
     L.kge_shard_count.argtypes = [vp, i64, i64, i64, vp, vp]

@@ -58,13 +58,13 @@ struct Engine {
     long long emit_launches = 0;   // timed launches since time_emit was switched on
     long long emit_seen = 0;       // all launches since then (time_emit = N times every N-th)
     // per-row 1/|row| table of the vectorised TransE emit kernel.  inv_valid = 1: it holds the norms of the CURRENT contents of
-    // inv_for_ent / inv_for_rel (bf16 gather mode: of their shadows) -- set by the pre-pass, kept by the full-table apply kernel
+    // inv_for_ent / inv_for_rel -- set by the pre-pass, kept by the full-table apply kernel
     // (which rewrites the entry of every row it changes), cleared by every other entry point that writes tables and by
     // kge_set_option("tables_changed") for writes the library cannot see (Config.set_parameters, restore, all-gathers)
     float *inv_norm = nullptr;
     int64_t inv_cap = 0;
     const float *inv_for_ent = nullptr, *inv_for_rel = nullptr;
-    int inv_valid = 0, inv_bf16 = 0;
+    int inv_valid = 0;
     int32_t *loss_limbs = nullptr;   // kge_loss_limbs_target: where the TransE emit kernel also writes its loss as limbs (null = nowhere)
     int counts_krel = 4;        // dense TransE path: virtual copies of the relation rows in the record sort (1 = none; measured 1/2/4/8/16/64: 4 best); a power of two
     int inv_carry = 1;          // 0 = always recompute the table in front of the emit kernel (test hook)
@@ -80,10 +80,6 @@ struct Engine {
     int hub_copies = 1;         // atomic TransH/TransD path: spread the relation-side rows over copies when a row takes >= 128 adds per step
     int lp_v1 = 0;              // test hook: link prediction through the generic predict kernel on materialised candidate batches
     int transr_v1 = 0;          // test hook: 1 = the 32x32x2 / 32-row-tile TransR kernels even where the v2 tiles apply; 2 = v2 with its all-tiles wgrad forced
-    // bf16 gather mode (non-parity): shadows of the two TransE tables, registered by kge_transe_set_bf16_shadow and kept current by
-    // the apply kernel; the emit kernel gathers from them when asked for exactly these master tables
-    uint16_t *shadow_ent = nullptr, *shadow_rel = nullptr;
-    const float *shadow_for_ent = nullptr, *shadow_for_rel = nullptr;
     int fb_occ4 = 1;            // projecting models at <= 4 elements per lane: the forward/backward body compiled for four waves per SIMD
     int persist_ahead = 1;      // persistent launch: idle teams sample the next batch during the forward/backward phase
     int persist_touch = 0;      // persistent launch: a group's rows requested together before its dependent gathers (measured: no gain)

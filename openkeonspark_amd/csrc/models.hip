@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void transe_emit_kernel(FbArgs a) {
 //   * the integer gradient vectors are packed int16 pairs (v_pk_add_i16), bytes only when stored;
 //   * one global_load_dwordx4 per row chunk.  Record dword w = lane + L*q holds elements 4w..4w+3
 //     ("natural" layout, flagged to the reducers).
-template <int L, int Q, int K, int WPE, bool INV_TAB, bool BF16 = false>
+template <int L, int Q, int K, int WPE, bool INV_TAB>
 __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
     constexpr int TEAMS = 256 / L;
     __shared__ float red[TEAMS];
@@ -256,23 +256,11 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
     bool valid[Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) valid[q] = 4 * (lane + L * q) < D;
-    // BF16 (the non-parity fast mode, Config.gather_dtype = "bf16"): rows are gathered from the bf16 SHADOW of the tables the
-    // optimizer keeps beside its fp32 master copy -- 8 bytes per lane instead of 16, same element -> lane mapping, fp32 arithmetic
     auto load4 = [&](const float *__restrict__ tab, long long row, float4 (&x)[Q]) {
-        if constexpr (BF16) {
-            const uint16_t *p = (tab == a.rel ? a.rel16 : a.ent16) + row * D;
+        const float *p = tab + row * D;
 #pragma unroll
-            for (int q = 0; q < Q; q++) {
-                const uint2 w = valid[q] ? *reinterpret_cast<const uint2 *>(p + 4 * (lane + L * q)) : make_uint2(0u, 0u);
-                x[q] = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u), __uint_as_float(w.y << 16),
-                                   __uint_as_float(w.y & 0xFFFF0000u));
-            }
-        } else {
-            const float *p = tab + row * D;
-#pragma unroll
-            for (int q = 0; q < Q; q++)
-                x[q] = valid[q] ? *reinterpret_cast<const float4 *>(p + 4 * (lane + L * q)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int q = 0; q < Q; q++)
+            x[q] = valid[q] ? *reinterpret_cast<const float4 *>(p + 4 * (lane + L * q)) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     float lsum = 0.f;
     for (long long b = (long long)blockIdx.x * TEAMS + team_in_block; b < a.n_pos; b += (long long)gridDim.x * TEAMS) {
@@ -467,22 +455,16 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
 
 // 1/max(|row|,1e-6): tf.nn.l2_normalize's rsqrt(max(sum x^2, 1e-12)) for every row of the two tables
 // The table's pre-pass, in the team shape of the apply kernel for this width (transe_team_shape) so that both produce the same bits
-template <int L, int C, bool BF16>
-__global__ __launch_bounds__(256) void row_inv_norm_kernel(const void *__restrict__ ent_, const void *__restrict__ rel_, long long E, long long R,
+template <int L, int C>
+__global__ __launch_bounds__(256) void row_inv_norm_kernel(const float *__restrict__ ent_, const float *__restrict__ rel_, long long E, long long R,
                                                            int D, float *__restrict__ out) {
     constexpr int TEAMS = 256 / L;
     const int lane = threadIdx.x % L;
     for (long long row = (long long)blockIdx.x * TEAMS + threadIdx.x / L; row < E + R; row += (long long)gridDim.x * TEAMS) {
         float x[C];
-        if constexpr (BF16) {
-            const uint16_t *p = row < E ? (const uint16_t *)ent_ + row * D : (const uint16_t *)rel_ + (row - E) * D;
+        const float *p = row < E ? ent_ + row * D : rel_ + (row - E) * D;
 #pragma unroll
-            for (int c = 0; c < C; c++) { const int e = lane + L * c; x[c] = e < D ? __uint_as_float((uint32_t)p[e] << 16) : 0.f; }
-        } else {
-            const float *p = row < E ? (const float *)ent_ + row * D : (const float *)rel_ + (row - E) * D;
-#pragma unroll
-            for (int c = 0; c < C; c++) { const int e = lane + L * c; x[c] = e < D ? p[e] : 0.f; }
-        }
+        for (int c = 0; c < C; c++) { const int e = lane + L * c; x[c] = e < D ? p[e] : 0.f; }
         const float inv = row_inv_norm<L, C>(x);
         if (lane == 0) out[row] = inv;
     }
@@ -513,18 +495,15 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
         // the per-row inverse-norm table costs one sweep of both tables per step: only while they are
         // cache-sized (FB15k-237 x 200: 11.8 MB); beyond 256 MB the norms are computed from the gathered rows
         const bool inv_tab = a.inv_norm != nullptr;
-        const bool bf16 = a.ent16 != nullptr;
         Engine &eng0 = engine();
         // the table is carried over from the previous step when the full-table apply kernel kept it current (transe_counts.hip)
-        const bool carried = eng0.inv_carry && eng0.inv_valid && eng0.inv_for_ent == a.ent && eng0.inv_for_rel == a.rel && eng0.inv_bf16 == (bf16 ? 1 : 0);
+        const bool carried = eng0.inv_carry && eng0.inv_valid && eng0.inv_for_ent == a.ent && eng0.inv_for_rel == a.rel;
         if (inv_tab && !carried) {
             long long nb = (a.ent_total + a.rel_total + TEAMS - 1) / TEAMS;
             if (nb > 2048) nb = 2048;
-            if (bf16) hipLaunchKernelGGL((row_inv_norm_kernel<L, C, true>), dim3((unsigned)nb), dim3(256), 0, stream, (const void *)a.ent16, (const void *)a.rel16,
-                                         (long long)a.ent_total, (long long)a.rel_total, a.D, const_cast<float *>(a.inv_norm));
-            else hipLaunchKernelGGL((row_inv_norm_kernel<L, C, false>), dim3((unsigned)nb), dim3(256), 0, stream, (const void *)a.ent, (const void *)a.rel,
-                                    (long long)a.ent_total, (long long)a.rel_total, a.D, const_cast<float *>(a.inv_norm));
-            eng0.inv_for_ent = a.ent; eng0.inv_for_rel = a.rel; eng0.inv_bf16 = bf16 ? 1 : 0; eng0.inv_valid = 1;
+            hipLaunchKernelGGL((row_inv_norm_kernel<L, C>), dim3((unsigned)nb), dim3(256), 0, stream, a.ent, a.rel,
+                               (long long)a.ent_total, (long long)a.rel_total, a.D, const_cast<float *>(a.inv_norm));
+            eng0.inv_for_ent = a.ent; eng0.inv_for_rel = a.rel; eng0.inv_valid = 1;
         }
         Engine &eng = engine();
         const int slot = (int)(eng.emit_launches % Engine::kEmitRing);
@@ -533,8 +512,7 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
             if (!eng.ev_emit0[slot]) { (void)hipEventCreate(&eng.ev_emit0[slot]); (void)hipEventCreate(&eng.ev_emit1[slot]); }
             (void)hipEventRecord(eng.ev_emit0[slot], stream);
         }
-        if (bf16 && inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        else if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         if (timed) { (void)hipEventRecord(eng.ev_emit1[slot], stream); eng.emit_launches++; }
         record_emit_done(stream);
@@ -632,9 +610,6 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
     }
     FbArgs a = {};
     a.inv_norm = use_inv_table ? e.inv_norm : nullptr;
-    if (e.shadow_ent && e.shadow_for_ent == ent && e.shadow_for_rel == rel && use_inv_table && m.ent_dim % 4 == 0 && !track_deferred) {
-        a.ent16 = e.shadow_ent; a.rel16 = e.shadow_rel;     // bf16 gather mode: these tables have a registered, current shadow
-    }
     a.group_list = track_deferred ? defer_list : nullptr; a.group_count = defer_count;
     a.ent = ent; a.rel = rel; a.g_ent = resid_ent; a.g_rel = resid_rel;
     a.bh = d_h; a.bt = d_t; a.br = d_r;

@@ -28,7 +28,6 @@ struct FbArgs {
     // kernel walks group_list[0 .. *group_count) instead of 0 .. n_pos
     int32_t *group_list;
     int32_t *group_count;
-    const uint16_t *ent16, *rel16;   // bf16 shadows of ent / rel (non-parity gather mode of the vectorised emit kernel), else null
     const float *inv_norm;  // [E+R] 1/|row| of ent_embeddings then rel_embeddings, refreshed per step (vectorised emit)
     // float-record path (TransH / TransD, float_records in transe_counts.hip): instead of an atomic row add, a
     // gradient row is STORED as record m = slot*n_pos + b with its destination in the VIRTUAL row space

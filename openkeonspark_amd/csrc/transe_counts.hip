@@ -175,14 +175,6 @@ __device__ __forceinline__ void flush_run(int32_t *__restrict__ S, int D, int la
     }
 }
 
-// fp32 -> bf16, round to nearest even (NaN kept quiet)
-__device__ __forceinline__ uint16_t bf16_rne(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-
 // d/dx of the normalised row applied to the integer sign sum: unit * (1/|x|) * (S - x^ <x^,S>), with every
 // operation individually rounded so that all apply kernels agree bit for bit given the same reduction order
 __device__ __forceinline__ float count_grad(float unit, float inv, float s, float d, float xn) {
@@ -1015,10 +1007,9 @@ struct ApplyArgs {
     const int32_t *row_list, *n_rows;
     float *p2, *m2, *v2, *resid2;
     long long E;
-    uint16_t *sh, *sh2;   // bf16 shadows of p / p2 (gather mode "bf16"), kept equal to the rounded master copy; null otherwise
     long long row_lo;   // dense form on a row RANGE [row_lo, rows): S points at the image of row_lo (a rank's reduce-scattered chunk)
     float *inv_out;     // dense full-table form: the emit kernel's 1/|row| table ([E + R], row-space index), refreshed for every row rewritten
-                        // here so that the next step needs no pre-pass; with bf16 shadows the norm is that of the ROUNDED row (what is gathered)
+                        // here so that the next step needs no pre-pass
 };
 
 template <int L, int C, bool SPARSE>
@@ -1031,8 +1022,7 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
     for (long long i = a.row_lo + (long long)blockIdx.x * TEAMS + threadIdx.x / L; i < n_rows; i += (long long)gridDim.x * TEAMS) {
         long long row = SPARSE ? (long long)a.row_list[i] : i;
         float *table = a.p, *mt = a.m, *vt = a.v, *rt = a.resid;
-        uint16_t *sh = a.sh;
-        if (row >= a.E) { row -= a.E; table = a.p2; mt = a.m2; vt = a.v2; rt = a.resid2; sh = a.sh2; }
+        if (row >= a.E) { row -= a.E; table = a.p2; mt = a.m2; vt = a.v2; rt = a.resid2; }
         int32_t *Sp = a.S + (i - a.row_lo) * a.D;
         float *rp = SPARSE ? nullptr : rt + row * a.D;
         float s[C], rs[C];
@@ -1068,7 +1058,7 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
             for (int c = 0; c < C; c++) g[c] = 0.f;
         }
         float *pp = table + row * a.D;
-        float xnew[C];      // the row as it stands after this update (bf16 gather mode: as its shadow holds it)
+        float xnew[C];      // the row as it stands after this update
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const int e = tm.lane + L * c;
@@ -1085,13 +1075,11 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
                 *mp = mi; *vp = vi;
                 pn = __fsub_rn(x[c], __fdiv_rn(__fmul_rn(a.lr, mi), __fadd_rn(__fsqrt_rn(vi), a.eps)));
                 pp[e] = pn;
-                if (!SPARSE && sh) sh[row * a.D + e] = bf16_rne(pn);
             } else if (g[c] != 0.f) {
                 pn = __fsub_rn(x[c], __fmul_rn(a.lr, g[c]));
                 pp[e] = pn;
-                if (!SPARSE && sh) sh[row * a.D + e] = bf16_rne(pn);
             }
-            xnew[c] = (!SPARSE && sh) ? __uint_as_float((uint32_t)bf16_rne(pn) << 16) : pn;
+            xnew[c] = pn;
             if (!SPARSE && touched != 0.f) { Sp[e] = 0; if (rs[c] != 0.f) rp[e] = 0.f; }
         }
         if constexpr (!SPARSE) {
@@ -1430,18 +1418,14 @@ int kge_transe_apply_counts_range(const kge_model_desc *m, float *const d_p[2], 
     ApplyArgs a = {};
     a.p = d_p[0]; a.p2 = d_p[1]; a.resid = d_resid[0]; a.resid2 = d_resid[1];
     if (adam) { a.m = d_m[0]; a.m2 = d_m[1]; a.v = d_v[0]; a.v2 = d_v[1]; }
-    {
-        Engine &e = engine();
-        if (e.shadow_ent && e.shadow_for_ent == d_p[0] && e.shadow_for_rel == d_p[1]) { a.sh = e.shadow_ent; a.sh2 = e.shadow_rel; }
-    }
     a.S = d_counts_chunk; a.rows = row_hi; a.row_lo = row_lo; a.E = m->ent_total; a.D = m->ent_dim;
     a.unit = 1.0f / (float)denom; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.adam = adam;
     {
         // the emit kernel's 1/|row| table stays current only when THIS launch rewrites its entries: the whole row space of exactly
-        // the tables it was computed for, in the same gather mode; any other update of those tables makes it stale
+        // the tables it was computed for; any other update of those tables makes it stale
         Engine &e = engine();
         const bool keeps = e.inv_carry && e.inv_valid && e.inv_norm && row_lo == 0 && row_hi == all_rows && e.inv_for_ent == d_p[0] &&
-                           e.inv_for_rel == d_p[1] && e.inv_cap >= all_rows && e.inv_bf16 == (a.sh ? 1 : 0);
+                           e.inv_for_rel == d_p[1] && e.inv_cap >= all_rows;
         if (keeps) a.inv_out = e.inv_norm;
         else tables_written();
     }
@@ -1455,32 +1439,6 @@ int kge_transe_apply_counts_range(const kge_model_desc *m, float *const d_p[2], 
     KGE_SHAPE_DISPATCH(D, KGE_APPLY2)
 #undef KGE_APPLY2
     return hip_check(hipGetLastError(), "apply counts launch");
-}
-
-namespace kge { namespace {
-__global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, long long n) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = bf16_rne(src[i]);
-}
-} }
-
-int kge_transe_set_bf16_shadow(const kge_model_desc *m, const float *d_ent, const float *d_rel, uint16_t *d_ent16, uint16_t *d_rel16,
-                               void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    Engine &e = engine();
-    if (!d_ent16 || !d_rel16) {      // unregister: back to fp32 gathers
-        e.shadow_ent = e.shadow_rel = nullptr; e.shadow_for_ent = e.shadow_for_rel = nullptr;
-        tables_written();
-        return KGE_OK;
-    }
-    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_set_bf16_shadow: no usable HIP device");
-    if (!m || !d_ent || !d_rel || m->model != KGE_TRANSE || m->ent_dim % 4)
-        return fail(KGE_ERR_BAD_ARG, "kge_transe_set_bf16_shadow: TransE with an embedding width that is a multiple of 4");
-    const long long ne = m->ent_total * (long long)m->ent_dim, nr = m->rel_total * (long long)m->ent_dim;
-    hipLaunchKernelGGL(to_bf16_kernel, dim3(2048), dim3(256), 0, stream, d_ent, d_ent16, ne);
-    hipLaunchKernelGGL(to_bf16_kernel, dim3(256), dim3(256), 0, stream, d_rel, d_rel16, nr);
-    e.shadow_ent = d_ent16; e.shadow_rel = d_rel16; e.shadow_for_ent = d_ent; e.shadow_for_rel = d_rel;
-    tables_written();
-    return hip_check(hipGetLastError(), "bf16 shadow refresh launch");
 }
 
 int kge_transe_apply_counts_tables(const kge_model_desc *m, float *const d_p[2], float *const d_m[2], float *const d_v[2],
