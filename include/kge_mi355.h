@@ -110,6 +110,10 @@ const char *kge_version(void);
 /* engine options (testing / measurement).
  *   "counts_force_sort": 1 = order the sign-count records with rocPRIM's radix sort instead of the
  *                        hand-written two-level counting sort (default 0)
+ *   "counts_fused":      1 (default) = kge_transe_train_step_counts sums the records of a row and applies the optimizer to it in one
+ *                        kernel (rows of up to 3 x team-width records; longer rows and relation rows go through the count image);
+ *                        0 = the two-kernel form (segmented sum into the image, then kge_transe_apply_counts_tables).  Same bits.
+ *   "counts_fused_cap":  test hook: rows of more than this many records take the image path (0 = the kernel's capacity)
  *   "inv_table_max_bytes": the TransE emit kernel reads 1/|row| from a per-row table rebuilt every step while
  *                        the two tables are at most this many bytes (default 256 MiB); larger tables (or 0)
  *                        compute the norms from the gathered rows
@@ -311,6 +315,19 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
                               int32_t *d_counts, float *d_resid_ent, float *d_resid_rel, float *d_loss, void *stream);
 int kge_transe_apply_counts(float *d_p, float *d_m, float *d_v, int32_t *d_counts, float *d_resid, int64_t rows, int32_t dim,
                             INT denom, int32_t adam, float lr, float beta1, float beta2, float eps, void *stream);
+/* The whole single-process step of the sign-count path in one call -- what sess.run([train_op, loss, global_step]) does for TransE
+ * (distribute_training.py:95-101,282): kge_transe_forward_counts followed by kge_transe_apply_counts_tables, with the middle fused
+ * where the shape allows (widths that are multiples of 4, tables that take the bucket sort): the negatives' records shrink to two
+ * bits per element, and the rows whose records fit one team are summed in registers and updated right there -- no count image, no
+ * second pass -- by the same per-row arithmetic as the apply kernel (bit-identical results; tests/test_gpu_models.py).  Longer
+ * rows, relation rows and rows without records go through `d_counts` (zero on entry, zero on return) and one apply launch.
+ * sampler_shaped = 1: the batch came from kge_sampling_device (no deferral bookkeeping, no fp32 pass, d_resid tables not read);
+ * 0: any batch, d_resid [E,D] / [R,D] (zero on entry and return) take the exact fp32 gradients of groups that are not
+ * sampler-shaped.  d_m / d_v may be NULL for SGD (adam = 0, lr); Adam: lr = lr_t. */
+int kge_transe_train_step_counts(const kge_model_desc *m, float *const d_p[2], float *const d_m[2], float *const d_v[2], const int32_t *d_h,
+                                 const int32_t *d_t, const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom, int32_t *d_counts,
+                                 float *const d_resid[2], int32_t sampler_shaped, int32_t adam, float lr, float beta1, float beta2, float eps,
+                                 float *d_loss, void *stream);
 /* both tables ([0] = ent_embeddings, [1] = rel_embeddings; d_counts = the whole [(E+R), D] image) in one launch */
 int kge_transe_apply_counts_tables(const kge_model_desc *m, float *const d_p[2], float *const d_m[2], float *const d_v[2],
                                    int32_t *d_counts, float *const d_resid[2], INT denom, int32_t adam, float lr, float beta1,

@@ -807,12 +807,21 @@ class Config(object):
             if target != getattr(self, "_limbs_target", 0):
                 self.lib.kge_loss_limbs_target(ctypes.c_void_p(target) if target else None)
                 self._limbs_target = target
+            # one process: forward, segmented sum and optimizer in ONE call (kge_transe_train_step_counts) -- the rows whose records one
+            # team can hold are summed in registers and updated there, without the count image; `fused_counts = False` keeps the
+            # two-call form (the data-parallel step needs the image: it is what the ranks exchange)
+            one_call = not self._dp and bool(getattr(self, "fused_counts", True))
             try:
-                self.forward_counts(dev, n_pos, stride, denom, sampler_shaped=batch_h is None)
+                if one_call:
+                    self.step_counts(dev, n_pos, stride, denom, sampler_shaped=batch_h is None)
+                else:
+                    self.forward_counts(dev, n_pos, stride, denom, sampler_shaped=batch_h is None)
             finally:
                 if ahead:                              # launched on its own if the step's path had no scatter kernel -- and
                     self._flush_next_batch()           # also when the forward call failed: an armed sampler never outlives its buffers
-            if self._dp:
+            if one_call:
+                pass
+            elif self._dp:
                 # int32 SUM is exact: rank g receives the summed counts of ITS rows, updates them, and the updated rows go round
                 self._dp_exchange(self._counts, self._counts_own, lambda k: self.apply_counts(denom, own=True, piece=k), counts=True)
                 self.tables_changed()
@@ -1101,6 +1110,19 @@ class Config(object):
             dev_batch[0].data_ptr(), dev_batch[1].data_ptr(), dev_batch[2].data_ptr(), n_pos,
             self.negative_ent + self.negative_rel, stride, denom, self._counts.data_ptr(),
             resid[0], resid[1], self._loss.data_ptr(), self._stream()), self.lib)
+
+    def step_counts(self, dev_batch, n_pos, stride, denom, sampler_shaped=False):
+        """TransE sign-count step in one call: forward_counts + apply_counts with the middle fused on the device
+        (include/kge_mi355.h kge_transe_train_step_counts; distribute_training.py:95-101,282).  Same bits as the two calls."""
+        lr = float(self._adam_lr_t()) if self._adam else float(self.alpha)
+        _lib.check(self.lib.kge_transe_train_step_counts(
+            ctypes.byref(self._desc), self._tab_ptrs, self._adam_m_ptrs if self._adam else None, self._adam_v_ptrs if self._adam else None,
+            dev_batch[0].data_ptr(), dev_batch[1].data_ptr(), dev_batch[2].data_ptr(), n_pos, self.negative_ent + self.negative_rel,
+            stride, denom, self._counts.data_ptr(), self._grad_ptrs, 1 if sampler_shaped else 0, 1 if self._adam else 0, lr,
+            self.adam_beta1, self.adam_beta2, self.adam_epsilon, self._loss.data_ptr(), self._stream()), self.lib)
+        if self._adam:
+            self._adam_advance()
+        self.global_step += 1
 
     def apply_counts(self, denom, own=False, piece=0):
         """Normalise-backward on the summed counts + SGD / TF1 Adam, both tables in one launch

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void transe_emit_kernel(FbArgs a) {
 //   * the integer gradient vectors are packed int16 pairs (v_pk_add_i16), bytes only when stored;
 //   * one global_load_dwordx4 per row chunk.  Record dword w = lane + L*q holds elements 4w..4w+3
 //     ("natural" layout, flagged to the reducers).
-template <int L, int Q, int K, int WPE, bool INV_TAB>
+template <int L, int Q, int K, int WPE, bool INV_TAB, bool REC2 = false>
 __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
     constexpr int TEAMS = 256 / L;
     __shared__ float red[TEAMS];
@@ -422,7 +422,20 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
                             At_lo[q] += s_lo * kt; At_hi[q] += s_hi * kt;
                             Ar_lo[q] += s_lo * kr; Ar_hi[q] += s_hi * kr;
                         }
-                        store_record<L, Q>(a, lane, m, rec);
+                        if constexpr (REC2) {
+                            // bytes {-1, 0, +1} -> 2-bit fields (value + 1) of ONE byte per lane: low two bits of every byte, + 1,
+                            // then the four fields gathered into the top byte by a carry-free multiply (2-bit fields at bits 0, 8, 16,
+                            // 24 times 2^24 + 2^18 + 2^12 + 2^6 land at bits 24, 26, 28, 30; every other partial product falls on a
+                            // bit position of its own below 24 or beyond 31)
+                            uint8_t *p2 = a.rec2 + ((long long)(k0 + kk + u) * a.n_pos + b) * (long long)(L * Q);
+#pragma unroll
+                            for (int q = 0; q < Q; q++) {
+                                const uint32_t f = ((rec[q] & 0x03030303u) + 0x01010101u) & 0x03030303u;
+                                if (valid[q]) p2[lane + L * q] = (uint8_t)((f * 0x01041040u) >> 24);
+                            }
+                        } else {
+                            store_record<L, Q>(a, lane, m, rec);
+                        }
                         if (lane == kk + u) my_dst = code[u] == 2 ? rel_row0 + row[u] : row[u];
                     }
                 }
@@ -512,7 +525,10 @@ static void launch_emit(const FbArgs &a_in, float *d_loss, hipStream_t stream) {
             if (!eng.ev_emit0[slot]) { (void)hipEventCreate(&eng.ev_emit0[slot]); (void)hipEventCreate(&eng.ev_emit1[slot]); }
             (void)hipEventRecord(eng.ev_emit0[slot], stream);
         }
-        if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        if (a.rec2) {
+            if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        } else if (inv_tab) hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((transe_emit_vec_kernel<L, (C + 3) / 4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
         if (timed) { (void)hipEventRecord(eng.ev_emit1[slot], stream); eng.emit_launches++; }
         record_emit_done(stream);
@@ -581,7 +597,9 @@ int transe_deferred_groups(int32_t *out) {
 
 int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *rel, float *resid_ent, float *resid_rel,
                        const int32_t *d_h, const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
-                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream, bool track_deferred) {
+                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream, bool track_deferred,
+                       uint8_t *rec2) {
+    // rec2: 2-bit records for the negatives (FbArgs::rec2; widths that are multiples of 4 only -- the caller checks); null = int8
     // track_deferred = false: the caller guarantees sampler-shaped negatives (a device-sampled batch): no
     // deferral list, no counter reset, no fp32 pass
     Engine &e = engine();
@@ -617,7 +635,7 @@ int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *r
     a.D = m.ent_dim; a.margin = m.margin; a.unit = 1.0f / (float)denom;
     a.loss_partials = e.dev.loss_partials;
     a.negative_rel = m.negative_rel;
-    a.rec = rec; a.dst = dst; a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total; a.krel = 1;
+    a.rec = rec; a.rec2 = (m.ent_dim % 4 == 0) ? rec2 : nullptr; a.dst = dst; a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total; a.krel = 1;
     a.loss_limbs = track_deferred ? nullptr : e.loss_limbs;   // (with a deferred pass the loss is finalised by loss_finalize_kernel: the caller converts it)
     while (a.krel * 2 <= krel) a.krel *= 2;      // a power of two: the kernels take b & (krel - 1)
     const int D = a.D;

@@ -23,6 +23,12 @@ struct FbArgs {
     // TransE sign-count path (transe_counts.hip): int8 gradient records + destination rows
     uint32_t *rec;
     int32_t *dst;
+    // rec2 != nullptr (the fused single-process step, transe_counts.hip segapply_kernel): the record of NEGATIVE slot 3 + k of group
+    // b is not an int8 record in `rec` but a 2-bit one here -- record (k * n_pos + b), one BYTE per lane and float4 chunk (L * Q
+    // bytes per record), element j of the lane's four as the 2-bit field (sign + 1) in {0, 1, 2} at bits 2j.  A negative's
+    // gradient w.r.t. its one new normalised vector is +-sign(e): two bits per element say it all, and the negatives are 25 of
+    // the 28 records of a bench group (64 B instead of 256 B each).  Slots 0..2 (sums of up to 2 n signs) stay int8 in `rec`.
+    uint8_t *rec2;
     int ent_total, rel_total, krel;
     // indirection for the deferred groups of the sign-count path: when group_list != nullptr the
     // kernel walks group_list[0 .. *group_count) instead of 0 .. n_pos

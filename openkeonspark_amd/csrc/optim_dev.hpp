@@ -2,6 +2,7 @@
 // persistent multi-step launch of persist.hip): SGD p -= lr*g and TF1-semantics Adam (_apply_sparse_shared op order).
 #pragma once
 #include "engine.hpp"
+#include "team.hpp"
 
 namespace kge {
 
@@ -48,15 +49,18 @@ __device__ __forceinline__ void sgd_sweep(float *__restrict__ p, float *__restri
 }
 
 __device__ __forceinline__ void adam_one(float &p, float &m, float &v, float g, float lr_t, float b1, float b2, float eps) {
-    // TF1 op order, each product rounded before the add (no fma contraction across the ops)
-    float mi = __fmul_rn(m, b1);
-    float vi = __fmul_rn(v, b2);
+    // TF1 op order, each product rounded before the add.  HIP's __fmul_rn / __fadd_rn are plain `*` / `+` (__clang_hip_math.h) and
+    // would be contracted into fma where the optimizer sees fit -- differently from one inlining context to the next: contraction is
+    // switched off for this body, so every caller gets the same bits
+#pragma clang fp contract(off)
+    float mi = mul_rn(m, b1);
+    float vi = mul_rn(v, b2);
     if (g != 0.f) {
-        mi = __fadd_rn(mi, __fmul_rn(g, 1.0f - b1));
-        vi = __fadd_rn(vi, __fmul_rn(__fmul_rn(g, g), 1.0f - b2));
+        mi = add_rn(mi, mul_rn(g, 1.0f - b1));
+        vi = add_rn(vi, mul_rn(mul_rn(g, g), 1.0f - b2));
     }
     m = mi; v = vi;
-    p = __fsub_rn(p, __fdiv_rn(__fmul_rn(lr_t, mi), __fadd_rn(__fsqrt_rn(vi), eps)));
+    p = sub_rn(p, __fdiv_rn(mul_rn(lr_t, mi), add_rn(__fsqrt_rn(vi), eps)));
 }
 
 __device__ __forceinline__ void adam_sweep(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v, float *__restrict__ g, long long n,

@@ -58,6 +58,23 @@ __device__ __forceinline__ float row_inv_norm(const float (&x)[C]) {
     return 1.0f / sqrtf(s >= 1e-12f ? s : 1e-12f);
 }
 
+// Single operations rounded on their own, which the optimizer may NOT contract into fma whatever they are inlined next to.
+// (HIP's __fmul_rn / __fadd_rn / __fsub_rn are plain `*` `+` `-` carrying the translation unit's contraction licence --
+// __clang_hip_math.h -- so a chain of them comes out fused in one kernel and unfused in the next: seen as one-ulp differences
+// between two kernels sharing one update function.  The pragma must sit where the operator is, not in the caller.)
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f ? 1.f : 0.f) - (x < 0.f ? 1.f : 0.f); }
 
 template <int L, int C>
@@ -83,9 +100,11 @@ struct Team {
         for (int c = 0; c < C; c++) { int e = lane + L * c; if (e < D) p[e] = v[c]; }
     }
     __device__ __forceinline__ float dot(const float (&a)[C], const float (&b)[C]) const {
+        // explicit fma chain: `s += a*b` is contracted or not as the optimizer sees fit in each inlining context, and kernels that
+        // must agree bit for bit (apply / fused segmented-sum-and-apply, transe_counts.hip) share this function
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < C; c++) s += a[c] * b[c];
+        for (int c = 0; c < C; c++) s = __builtin_fmaf(a[c], b[c], s);
         return team_sum<L>(s);
     }
     // tf.nn.l2_normalize: x * rsqrt(max(sum x^2, 1e-12))  (TransE.py:12-14)

@@ -31,7 +31,8 @@ namespace kge {
 void transe_team_shape(int D, int &L, int &C);
 int launch_transe_emit(const kge_model_desc &m, const float *ent, const float *rel, float *resid_ent, float *resid_rel,
                        const int32_t *d_h, const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
-                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream, bool track_deferred);
+                       int64_t denom, uint32_t *rec, int32_t *dst, int krel, float *d_loss, hipStream_t stream, bool track_deferred,
+                       uint8_t *rec2 = nullptr);
 
 int transe_deferred_groups(int32_t *out);
 
@@ -53,6 +54,12 @@ struct CtWork {
     int64_t cap_idx = 0;
     int32_t *bflag = nullptr;
     int64_t bflag_cap = 0;
+    // fused single-process step: the plan of segapply_kernel
+    int4 *chunks = nullptr;
+    int64_t chunks_cap = 0;
+    int32_t *n_chunks = nullptr;
+    uint8_t *row_state = nullptr;
+    int64_t row_state_cap = 0;
 };
 CtWork g_c;
 
@@ -111,6 +118,7 @@ __global__ void count_valid_kernel(const int32_t *__restrict__ sorted, int M, in
 }
 
 constexpr int CHUNK = 64;
+constexpr uint8_t kRowEmpty = 0, kRowDirect = 1, kRowImage = 2;   // fused step: per-row plan (bkt_sort_kernel<true>)
 
 // value held by lane `i` of the calling lane's L-lane team (i a compile-time constant where it matters: a full wave reads it
 // into an SGPR with v_readlane, narrower teams go through ds_bpermute)
@@ -178,7 +186,8 @@ __device__ __forceinline__ void flush_run(int32_t *__restrict__ S, int D, int la
 // d/dx of the normalised row applied to the integer sign sum: unit * (1/|x|) * (S - x^ <x^,S>), with every
 // operation individually rounded so that all apply kernels agree bit for bit given the same reduction order
 __device__ __forceinline__ float count_grad(float unit, float inv, float s, float d, float xn) {
-    return __fmul_rn(__fmul_rn(unit, inv), __fsub_rn(s, __fmul_rn(d, xn)));
+#pragma clang fp contract(off)
+    return mul_rn(mul_rn(unit, inv), sub_rn(s, mul_rn(d, xn)));
 }
 
 // Sparse-row SGD on ONE row from its summed integer counts held in the NATURAL layout of the vectorised kernels
@@ -187,6 +196,7 @@ __device__ __forceinline__ float count_grad(float unit, float inv, float s, floa
 // handles it (which one does depends on where chunk boundaries fall, i.e. on the number of ranks).
 template <int L, int C>
 __device__ __forceinline__ void apply_row_nat(const int (&acc)[C], float *__restrict__ p, int D, int lane, float unit, float lr) {
+#pragma clang fp contract(off)   // (the same bits from both kernels that inline this body: see apply_row_update)
     constexpr int Q = (C + 3) / 4;
     float x[4 * Q], sv[4 * Q];
     float ss = 0.f;
@@ -219,8 +229,8 @@ __device__ __forceinline__ void apply_row_nat(const int (&acc)[C], float *__rest
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int c = 4 * q + j;
-                const float g = __fadd_rn(count_grad(unit, inv, sv[c], d, x[c] * inv), 0.f);
-                o[j] = g != 0.f ? __fsub_rn(x[c], __fmul_rn(lr, g)) : x[c];
+                const float g = add_rn(count_grad(unit, inv, sv[c], d, x[c] * inv), 0.f);
+                o[j] = g != 0.f ? sub_rn(x[c], mul_rn(lr, g)) : x[c];
                 any = any || g != 0.f;
             }
             if (any) *reinterpret_cast<float4 *>(p + e0) = make_float4(o[0], o[1], o[2], o[3]);
@@ -338,8 +348,10 @@ constexpr int BTILE = 4096;      // records per histogram / scatter tile
 __device__ __forceinline__ int bucket_of(int d, int rpb) { return d < 0 ? NB : d / rpb; }
 
 // bucket_total[b] += number of records of this tile that fall into bucket b
-__global__ __launch_bounds__(256) void bkt_hist_kernel(const int32_t *__restrict__ dst, int M, int rpb, int32_t *__restrict__ bucket_total) {
+__global__ __launch_bounds__(256) void bkt_hist_kernel(const int32_t *__restrict__ dst, int M, int rpb, int32_t *__restrict__ bucket_total,
+                                                       int32_t *__restrict__ plan_counter = nullptr) {
     __shared__ int hist[NB + 1];
+    if (plan_counter && blockIdx.x == 0 && threadIdx.x == 0) plan_counter[0] = 0;   // fused step: the chunk counter bkt_sort_kernel<true> adds to
     for (int i = threadIdx.x; i <= NB; i += 256) hist[i] = 0;
     __syncthreads();
     const int base = blockIdx.x * BTILE;
@@ -441,10 +453,24 @@ static void launch_bkt_scatter(int n_tiles, int M, int rpb, int32_t *totals, int
 // that the whole list is row-sorted and the register-accumulating segsum_kernel can consume it.
 // (An LDS-image reduction with ds_add per element was tried first: correct, but bound by the LDS
 // atomic rate -- 3.8 M wave-level ds_add per step -- at 230 us; registers + sorted runs take ~60.)
+// PLAN (the fused single-process step): the bucket also plans the work of segapply_kernel for its rows --
+//   row_state[row] for every ENTITY row of the bucket: kRowEmpty (no record), kRowDirect (all its records lie in ONE chunk:
+//   summed in registers and updated right there), kRowImage (more than `cap` records: summed into the count image by pieces);
+//   chunks: (first, end) positions in the sorted list + flag; a chunk holds WHOLE rows of at most `cap` records together (greedy, in
+//   row order), or -- flag 1 -- one piece of at most `cap` records of a longer row.  Chunk slots are taken from one global counter,
+//   one atomic per bucket.
+struct SegPlan {
+    int4 *chunks;          // [max_chunks]  (first, end, flag, 0)
+    int32_t *n_chunks;     // zeroed by the apply kernel that ends the step
+    uint8_t *row_state;    // [E]
+    int E, cap;
+};
+
+template <bool PLAN>
 __global__ __launch_bounds__(256) void bkt_sort_kernel(const int2 *__restrict__ pairs, const int32_t *__restrict__ bucket_start,
                                                        int rpb, int rows, int32_t *__restrict__ out_keys,
                                                        int32_t *__restrict__ out_ids, int32_t *__restrict__ bucket_total,
-                                                       int32_t *__restrict__ cursor) {
+                                                       int32_t *__restrict__ cursor, SegPlan plan) {
     extern __shared__ int lds_h[];   // [rpb] histogram, then running offsets
     const int b = blockIdx.x;
     const int row0 = b * rpb;
@@ -455,7 +481,11 @@ __global__ __launch_bounds__(256) void bkt_sort_kernel(const int2 *__restrict__ 
     if (row0 >= rows) return;
     const int start = bucket_start[b], end = bucket_start[b + 1];
     for (int i = threadIdx.x; i < rpb; i += 256) lds_h[i] = 0;
-    if (end == start) return;
+    if (end == start) {
+        if constexpr (PLAN)
+            for (int i = threadIdx.x; i < rpb; i += 256) if (row0 + i < plan.E) plan.row_state[row0 + i] = kRowEmpty;
+        return;
+    }
     // the first 256*PC pairs of the bucket (all of it, normally) are read ONCE, into registers, for both passes
     constexpr int PC = 8;
     int2 pr[PC];
@@ -505,6 +535,44 @@ __global__ __launch_bounds__(256) void bkt_sort_kernel(const int2 *__restrict__ 
         const int pos = start + atomicAdd(&lds_h[q.y - row0], 1);
         out_keys[pos] = q.y;
         out_ids[pos] = q.x;
+    }
+    if constexpr (PLAN) {
+        __syncthreads();     // lds_h[i] is now the END offset of row i inside the bucket (= the start of row i + 1)
+        const int cap = plan.cap;
+        for (int i = threadIdx.x; i < rpb; i += 256) {
+            const int row = row0 + i;
+            if (row < plan.E && row < rows) {
+                const int c = lds_h[i] - (i ? lds_h[i - 1] : 0);
+                plan.row_state[row] = c == 0 ? kRowEmpty : (c > cap ? kRowImage : kRowDirect);
+            }
+        }
+        if (threadIdx.x == 0) {
+            // two passes over the bucket's rows by one thread (a few dozen rows): count the chunks, take that many slots with ONE
+            // atomic, write them
+            int base = 0;
+            for (int pass = 0; pass < 2; pass++) {
+                int n = 0, cur_first = 0, cur_n = 0;
+                auto put = [&](int first, int last, int flag) {
+                    if (pass) plan.chunks[base + n] = make_int4(start + first, start + last, flag, 0);
+                    n++;
+                };
+                const int r_hi = min(rpb, rows - row0);
+                for (int i = 0; i < r_hi; i++) {
+                    const int lo = i ? lds_h[i - 1] : 0, c = lds_h[i] - lo;
+                    if (c == 0) continue;
+                    if (c > cap) {
+                        if (cur_n) { put(cur_first, cur_first + cur_n, 0); cur_n = 0; }
+                        for (int off = 0; off < c; off += cap) put(lo + off, lo + min(off + cap, c), 1);
+                    } else {
+                        if (cur_n + c > cap) { put(cur_first, cur_first + cur_n, 0); cur_n = 0; }
+                        if (cur_n == 0) cur_first = lo;
+                        cur_n += c;
+                    }
+                }
+                if (cur_n) put(cur_first, cur_first + cur_n, 0);
+                if (pass == 0) base = n ? atomicAdd(plan.n_chunks, n) : 0;
+            }
+        }
     }
 }
 
@@ -576,7 +644,7 @@ __device__ __forceinline__ void flush_run_f32(const FloatRowSpace &rs, int D, in
     for (int c = 0; c < C; c++) {
         const int e = lane + L * c;
         if (e < D) {
-            const float v = __fmul_rn(rs.scale, acc[c]);
+            const float v = mul_rn(rs.scale, acc[c]);
             if (atomic) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(p + e), v);
             else p[e] += v;
         }
@@ -853,8 +921,8 @@ int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t 
         int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
         hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals);
         launch_bkt_scatter(n_tiles, (int)M, rpb, totals, cursor, pairs, stream);
-        hipLaunchKernelGGL(bkt_sort_kernel, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
-                           g_c.dst_sorted, g_c.ids_sorted, totals, cursor);
+        hipLaunchKernelGGL(bkt_sort_kernel<false>, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
+                           g_c.dst_sorted, g_c.ids_sorted, totals, cursor, SegPlan());
         n_valid_p = g_c.bucket_start + NB;
     } else {
         int blocks = (int)((M + 255) / 256);
@@ -920,8 +988,8 @@ int pair_records_reduce(int model, int64_t M, int64_t n_int8, int D, int rd, int
         int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
         hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals);
         launch_bkt_scatter(n_tiles, (int)M, rpb, totals, cursor, pairs, stream);
-        hipLaunchKernelGGL(bkt_sort_kernel, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
-                           g_c.dst_sorted, g_c.ids_sorted, totals, cursor);
+        hipLaunchKernelGGL(bkt_sort_kernel<false>, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
+                           g_c.dst_sorted, g_c.ids_sorted, totals, cursor, SegPlan());
         n_valid_p = g_c.bucket_start + NB;   // start of the trash bucket == number of live records
     } else {
         // larger key spaces (e.g. FB15k: 14 951 entities x 1 345 relations): rocPRIM's radix sort on the same keys
@@ -1008,9 +1076,79 @@ struct ApplyArgs {
     float *p2, *m2, *v2, *resid2;
     long long E;
     long long row_lo;   // dense form on a row RANGE [row_lo, rows): S points at the image of row_lo (a rank's reduce-scattered chunk)
+    const uint8_t *row_state;   // fused step: per ENTITY row, what segapply_kernel did with it (kRowDirect rows are skipped here); else null
     float *inv_out;     // dense full-table form: the emit kernel's 1/|row| table ([E + R], row-space index), refreshed for every row rewritten
                         // here so that the next step needs no pre-pass
 };
+
+// One row's update from its summed counts s[] (team layout: lane l holds elements l, l+L, ...), residual gradient rs[] and --
+// `have` -- its parameter / moment rows already in registers.  THE arithmetic of the count path's optimizer step: the dense apply
+// kernel, the row-list (sparse / lazy-Adam) kernel and the fused segmented-sum-and-apply kernel all call it, so a row gets the
+// same bits whichever of them handles it.  Returns false where SGD leaves an untouched row alone.
+//   i : the row's index in the [(E + R), D] row space (image row, 1/|row| table entry);  Sp / rp : its image / residual rows to
+//   re-zero (null: nothing to re-zero)
+template <int L, int C, bool SPARSE>
+__device__ __forceinline__ bool apply_row_update(const Team<L, C> &tm, const ApplyArgs &a, float *table, float *mt, float *vt, long long row,
+                                                 long long i, const float (&s)[C], const float (&rs)[C], float (&x)[C], float (&m_old)[C],
+                                                 float (&v_old)[C], bool have, int32_t *Sp, float *rp) {
+    // HIP's __fmul_rn / __fadd_rn are plain `*` / `+` (__clang_hip_math.h): left to the optimizer they are contracted into fma
+    // differently in each kernel this body is inlined into (seen: v of the fused kernel one ulp off the apply kernel's).  With
+    // contraction off for this body every caller computes the same bits.
+#pragma clang fp contract(off)
+    float g[C];
+    float touched = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; c++) touched += (s[c] != 0.f || rs[c] != 0.f) ? 1.f : 0.f;
+    touched = team_sum<L>(touched);
+    if (touched == 0.f && !a.adam) return false;  // SGD leaves untouched rows alone; TF1 Adam moves every row
+    if (!have) {
+        tm.load(table, row, x);
+        if (a.adam) { tm.load(mt, row, m_old); tm.load(vt, row, v_old); }
+    }
+    if (touched != 0.f) {
+        float xn[C], inv; bool uc;
+        tm.normalize(x, xn, inv, uc);
+        float d = tm.dot(xn, s);
+        if (!uc) d = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) g[c] = add_rn(count_grad(a.unit, inv, s[c], d, xn[c]), rs[c]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c++) g[c] = 0.f;
+    }
+    float *pp = table + row * a.D;
+    float xnew[C];      // the row as it stands after this update
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int e = tm.lane + L * c;
+        xnew[c] = 0.f;
+        if (e >= a.D) continue;
+        float pn = x[c];
+        if (a.adam) {
+            float *mp = mt + row * a.D + e, *vp = vt + row * a.D + e;
+            float mi = mul_rn(m_old[c], a.b1), vi = mul_rn(v_old[c], a.b2);
+            if (g[c] != 0.f) {
+                mi = add_rn(mi, mul_rn(g[c], 1.0f - a.b1));
+                vi = add_rn(vi, mul_rn(mul_rn(g[c], g[c]), 1.0f - a.b2));
+            }
+            *mp = mi; *vp = vi;
+            pn = sub_rn(x[c], __fdiv_rn(mul_rn(a.lr, mi), add_rn(__fsqrt_rn(vi), a.eps)));
+            pp[e] = pn;
+        } else if (g[c] != 0.f) {
+            pn = sub_rn(x[c], mul_rn(a.lr, g[c]));
+            pp[e] = pn;
+        }
+        xnew[c] = pn;
+        if (!SPARSE && touched != 0.f) { if (Sp) Sp[e] = 0; if (rp && rs[c] != 0.f) rp[e] = 0.f; }
+    }
+    if constexpr (!SPARSE) {
+        if (a.inv_out) {       // (wave-uniform: a kernel argument)
+            const float inv_new = row_inv_norm<L, C>(xnew);
+            if (tm.lane == 0) a.inv_out[i] = inv_new;
+        }
+    }
+    return true;
+}
 
 template <int L, int C, bool SPARSE>
 __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
@@ -1021,74 +1159,202 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
     const long long n_rows = SPARSE ? (long long)a.n_rows[0] : a.rows;
     for (long long i = a.row_lo + (long long)blockIdx.x * TEAMS + threadIdx.x / L; i < n_rows; i += (long long)gridDim.x * TEAMS) {
         long long row = SPARSE ? (long long)a.row_list[i] : i;
+        // behind the fused segmented-sum-and-apply kernel: the entity rows it has already updated from registers are skipped
+        if (!SPARSE && a.row_state && row < a.E && a.row_state[row] == kRowDirect) continue;
         float *table = a.p, *mt = a.m, *vt = a.v, *rt = a.resid;
         if (row >= a.E) { row -= a.E; table = a.p2; mt = a.m2; vt = a.v2; rt = a.resid2; }
         int32_t *Sp = a.S + (i - a.row_lo) * a.D;
-        float *rp = SPARSE ? nullptr : rt + row * a.D;
+        float *rp = (SPARSE || !rt) ? nullptr : rt + row * a.D;
         float s[C], rs[C];
-        float x[C], g[C], m_old[C], v_old[C];
+        float x[C], m_old[C], v_old[C];
         // TF1 Adam moves EVERY row: its parameter and moment rows are requested together with the counts, not after the
         // "touched?" reduction (one memory round trip per row instead of two)
         const bool every_row = !SPARSE && a.adam;
         if (every_row) {
             tm.load(table, row, x); tm.load(mt, row, m_old); tm.load(vt, row, v_old);
         }
-        float touched = 0.f;
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const int e = tm.lane + L * c;
             const int si = e < a.D ? Sp[e] : 0;
-            rs[c] = (!SPARSE && e < a.D) ? rp[e] : 0.f;
+            rs[c] = (rp && e < a.D) ? rp[e] : 0.f;
             s[c] = (float)si;
-            touched += (si != 0 || rs[c] != 0.f) ? 1.f : 0.f;
         }
-        touched = team_sum<L>(touched);
-        if (touched == 0.f && !a.adam) continue;  // SGD leaves untouched rows alone; TF1 Adam moves every row
-        if (!every_row) tm.load(table, row, x);
-        if (SPARSE && a.adam) { tm.load(mt, row, m_old); tm.load(vt, row, v_old); }   // lazy Adam: the listed rows only
-        if (touched != 0.f) {
-            float xn[C], inv; bool uc;
-            tm.normalize(x, xn, inv, uc);
-            float d = tm.dot(xn, s);
-            if (!uc) d = 0.f;
+        apply_row_update<L, C, SPARSE>(tm, a, table, mt, vt, row, i, s, rs, x, m_old, v_old, every_row, SPARSE ? nullptr : Sp, rp);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused segmented sum + optimizer step (single process, dense tables): stages 2b and 3 in one kernel, without the count image
+// for the rows whose records one team can hold.
+//
+// One team per CHUNK of the plan bkt_sort_kernel<true> made: whole rows of at most cap records together, or one piece of a longer
+// row.  The team sums each row's records in registers (natural layout: lane l holds elements 4l..4l+3) -- int8 records through
+// v_dot4 with a one-hot selector (one instruction per element), the negatives' 2-bit records (FbArgs::rec2) by spreading the
+// lane's byte into four byte-wide fields and adding them packed (five instructions per record, unpacked every <= 127 records) --
+// and at the end of a row
+//   * an entity row that lies wholly in this chunk is UPDATED here: its parameter / moment rows were requested when its first
+//     record was seen, the sums are turned into the team layout through LDS, and apply_row_update does exactly what the apply
+//     kernel would have done with the same sums (bit-identical to the two-kernel path, which the data-parallel step keeps);
+//   * a piece of a longer row and every relation row (virtual copies fold onto one row, and a hub relation has thousands of
+//     records) is added into the int32 count image with atomics; apply_counts_kernel then runs over those rows and over the rows
+//     without any record (TF1 Adam moves them too), skipping the rows updated here (row_state).
+// What this saves against segsum_kernel + apply_counts_kernel: the image traffic of the direct rows (written, read, re-zeroed:
+// 35 MB of a bench step), nearly all boundary atomics (a chunk of 64 sorted records there ends inside a row almost always), and
+// three quarters of the record bytes.
+// ---------------------------------------------------------------------------------------------
+struct SegApplyArgs {
+    const uint32_t *rec;     // int8 records [n8][RD dwords]
+    const uint8_t *rec2;     // 2-bit records [*][RD bytes], record id - n8
+    const int32_t *keys, *ids;
+    const int4 *chunks;
+    const int32_t *n_chunks;
+    long long n8;
+    int RD;
+    int32_t *S;              // count image
+    int fold_R;              // relations: key >= ap.E is copy (key - E) / fold_R of relation (key - E) % fold_R
+    ApplyArgs ap;
+};
+
+// entry i (wave-uniform, dynamic) of a list held as a[j] = entry (lane + L*j)
+template <int L, int J>
+__device__ __forceinline__ int entry_dyn(const int (&a)[J], int i) {
+    int v = a[0];
 #pragma unroll
-            for (int c = 0; c < C; c++) g[c] = __fadd_rn(count_grad(a.unit, inv, s[c], d, xn[c]), rs[c]);
+    for (int j = 1; j < J; j++) v = (i / L == j) ? a[j] : v;
+    if constexpr (L == 64) return __builtin_amdgcn_readlane(v, i % L);
+    else return __shfl(v, i % L, L);
+}
+
+template <int L, int C>
+__global__ __launch_bounds__(256) void segapply_kernel(SegApplyArgs sa) {
+    constexpr int TEAMS = 256 / L;
+    constexpr int Q = C / 4;
+    constexpr int J = 3;              // a chunk holds at most J*L records (the planner's cap)
+    constexpr int U = 16;             // records in flight per team
+    static_assert(C % 4 == 0, "natural record layout: four elements per lane and chunk");
+    __shared__ int32_t stage_all[256 * C];
+    int32_t *stage = stage_all + (threadIdx.x / L) * (L * C);
+    Team<L, C> tm;
+    tm.lane = threadIdx.x % L;
+    tm.D = sa.ap.D;
+    const int lane = tm.lane;
+    const ApplyArgs &ap = sa.ap;
+    const long long team = (long long)blockIdx.x * TEAMS + threadIdx.x / L;
+    if (team >= sa.n_chunks[0]) return;
+    const int4 ch = sa.chunks[team];
+    const int start = ch.x, n = ch.y - ch.x;
+    const bool piece = ch.z != 0;
+    int kl[J], idl[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int i = min(lane + L * j, n - 1);
+        kl[j] = sa.keys[start + i];
+        idl[j] = sa.ids[start + i];
+    }
+    int acc[C];
+    uint32_t pk[Q];
+#pragma unroll
+    for (int c = 0; c < C; c++) acc[c] = 0;
+#pragma unroll
+    for (int q = 0; q < Q; q++) pk[q] = 0u;
+    int n2 = 0;                       // 2-bit records added into pk since it was last unpacked
+    float x[C], mo[C], vo[C];
+    auto direct = [&](int key) { return !piece && key < ap.E; };
+    auto request = [&](int key) {     // the row's parameter / moment rows, asked for when its first record is seen
+        if (direct(key)) {
+            tm.load(ap.p, key, x);
+            if (ap.adam) { tm.load(ap.m, key, mo); tm.load(ap.v, key, vo); }
+        }
+    };
+    auto unpack = [&]() {             // pk fields hold sum (sign + 1) over n2 records
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[4 * q + j] += (int)((pk[q] >> (8 * j)) & 0xFFu) - n2;
+            pk[q] = 0u;
+        }
+        n2 = 0;
+    };
+    auto finish = [&](int key) {
+        unpack();
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+            *reinterpret_cast<int4 *>(stage + 4 * (lane + L * q)) = make_int4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        int si[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) { const int e = lane + L * c; si[c] = e < ap.D ? stage[e] : 0; acc[c] = 0; }
+        if (direct(key)) {
+            float sf[C], rs[C];
+            float *rp = ap.resid ? ap.resid + (long long)key * ap.D : nullptr;
+#pragma unroll
+            for (int c = 0; c < C; c++) { const int e = lane + L * c; sf[c] = (float)si[c]; rs[c] = (rp && e < ap.D) ? rp[e] : 0.f; }
+            apply_row_update<L, C, false>(tm, ap, ap.p, ap.m, ap.v, key, key, sf, rs, x, mo, vo, true, nullptr, rp);
         } else {
+            const long long row = key < ap.E ? key : ap.E + (key - ap.E) % sa.fold_R;
+            int32_t *p = sa.S + row * ap.D;
 #pragma unroll
-            for (int c = 0; c < C; c++) g[c] = 0.f;
+            for (int c = 0; c < C; c++) { const int e = lane + L * c; if (e < ap.D && si[c] != 0) atomicAdd(p + e, si[c]); }
         }
-        float *pp = table + row * a.D;
-        float xnew[C];      // the row as it stands after this update
+    };
+    int cur = entry_dyn<L, J>(kl, 0);
+    request(cur);
+    for (int i0 = 0; i0 < n; i0 += U) {
+        int k[U];
+        uint32_t w[U][Q];
+        unsigned two = 0;                          // bit u: record u of the batch is a 2-bit record
+        const int nb = min(U, n - i0);             // records of this batch
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-            const int e = tm.lane + L * c;
-            xnew[c] = 0.f;
-            if (e >= a.D) continue;
-            float pn = x[c];
-            if (a.adam) {
-                float *mp = mt + row * a.D + e, *vp = vt + row * a.D + e;
-                float mi = __fmul_rn(m_old[c], a.b1), vi = __fmul_rn(v_old[c], a.b2);
-                if (g[c] != 0.f) {
-                    mi = __fadd_rn(mi, __fmul_rn(g[c], 1.0f - a.b1));
-                    vi = __fadd_rn(vi, __fmul_rn(__fmul_rn(g[c], g[c]), 1.0f - a.b2));
-                }
-                *mp = mi; *vp = vi;
-                pn = __fsub_rn(x[c], __fdiv_rn(__fmul_rn(a.lr, mi), __fadd_rn(__fsqrt_rn(vi), a.eps)));
-                pp[e] = pn;
-            } else if (g[c] != 0.f) {
-                pn = __fsub_rn(x[c], __fmul_rn(a.lr, g[c]));
-                pp[e] = pn;
+        for (int u = 0; u < U; u++) {
+            const int i = min(i0 + u, n - 1);      // entries past n repeat the last record (never consumed): loads stay unconditional
+            k[u] = entry_dyn<L, J>(kl, i);
+            const long long id = entry_dyn<L, J>(idl, i);
+            if (id >= sa.n8) {
+                two |= 1u << u;
+                const uint8_t *p = sa.rec2 + (id - sa.n8) * sa.RD;
+#pragma unroll
+                for (int q = 0; q < Q; q++) w[u][q] = p[lane + L * q];
+            } else {
+                const uint32_t *p = sa.rec + id * sa.RD;
+#pragma unroll
+                for (int q = 0; q < Q; q++) w[u][q] = p[lane + L * q];
             }
-            xnew[c] = pn;
-            if (!SPARSE && touched != 0.f) { Sp[e] = 0; if (rs[c] != 0.f) rp[e] = 0.f; }
         }
-        if constexpr (!SPARSE) {
-            if (a.inv_out) {       // (wave-uniform: a kernel argument)
-                const float inv_new = row_inv_norm<L, C>(xnew);
-                if (tm.lane == 0) a.inv_out[i] = inv_new;
+        // consume the batch run by run: ONE copy of the accumulate block and ONE of the row finish in the code (the finish inlined at
+        // every record position made the kernel spill); the records of the current row are those from u0 on whose key equals `cur`
+        int u0 = 0;
+        while (u0 < nb) {
+            int stop = nb, next = cur;             // first position >= u0 of another row, and that row
+#pragma unroll
+            for (int u = U - 1; u >= 0; u--)
+                if (u >= u0 && u < nb && k[u] != cur) { stop = u; next = k[u]; }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (u < u0 || u >= stop) continue;
+                if ((two >> u) & 1u) {
+#pragma unroll
+                    for (int q = 0; q < Q; q++) {
+                        const uint32_t b = w[u][q];
+                        pk[q] += (b | (b << 6) | (b << 12) | (b << 18)) & 0x03030303u;
+                    }
+                    if (++n2 == 127) unpack();
+                } else {
+#pragma unroll
+                    for (int q = 0; q < Q; q++) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[4 * q + j] = __builtin_amdgcn_sdot4((int)w[u][q], 1 << (8 * j), acc[4 * q + j], false);
+                    }
+                }
+            }
+            u0 = stop;
+            if (u0 < nb) {
+                finish(cur);
+                cur = next;
+                request(cur);
             }
         }
     }
+    finish(cur);
 }
 
 #define KGE_SHAPE_DISPATCH(D, CALL)                                      \
@@ -1113,9 +1379,21 @@ int kge_transe_counts_supported(const kge_model_desc *m, INT n_neg) {
            m->ent_total + m->rel_total < (int64_t(1) << 30);
 }
 
-int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const float *d_rel, const int32_t *d_h,
-                              const int32_t *d_t, const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom,
-                              int32_t *d_counts, float *d_resid_ent, float *d_resid_rel, float *d_loss, void *stream_) {
+}  // extern "C"
+
+namespace kge { namespace {
+// optimizer half of the fused single-process step (kge_transe_train_step_counts); null = forward only (kge_transe_forward_counts)
+struct FusedOpt {
+    float *p[2], *m[2], *v[2];
+    int adam;
+    float lr, b1, b2, eps;
+    bool done = false;     // set where the fused kernels ran; false on return = the caller applies the image itself
+};
+} }
+
+static int forward_counts_impl(const kge_model_desc *m, const float *d_ent, const float *d_rel, const int32_t *d_h,
+                               const int32_t *d_t, const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom,
+                               int32_t *d_counts, float *d_resid_ent, float *d_resid_rel, float *d_loss, void *stream_, FusedOpt *fo) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_transe_forward_counts: no usable HIP device");
     if (!m || !kge_transe_counts_supported(m, n_neg)) return fail(KGE_ERR_UNSUPPORTED, "sign-count path: TransE, dim <= 1024, 1..63 negatives");
@@ -1138,14 +1416,79 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
         while (krel > 1 && (int64_t)krel * m->rel_total > 2 * (m->ent_total + m->rel_total)) krel >>= 1;   // copies stay a minor part of the row space
     }
     const int rows = (int)(m->ent_total + (int64_t)krel * m->rel_total);
-    rc = launch_transe_emit(*m, d_ent, d_rel, d_resid_ent, d_resid_rel, d_h, d_t, d_r, n_pos, n_neg, stride, denom, g_c.rec, g_c.dst,
-                            krel, d_loss, stream, d_resid_ent != nullptr && d_resid_rel != nullptr);
-    if (rc) return rc;
     const int D = m->ent_dim;
     const bool nat = D % 4 == 0;   // the vectorised emit kernel writes records in natural element order
+    const int rpb = (rows + NB - 1) / NB;
+    // the fused segmented-sum-and-apply path: natural-layout records, the bucket sort (whose buckets plan its chunks: one thread
+    // walks a bucket's rows, so buckets stay small), row ids that fit the plan
+    const bool fused = fo && nat && rpb <= 1024 && !engine().counts_force_sort && engine().counts_fused;
+    uint8_t *rec2 = fused ? reinterpret_cast<uint8_t *>(g_c.rec + (size_t)3 * (size_t)n_pos * rd) : nullptr;
+    rc = launch_transe_emit(*m, d_ent, d_rel, d_resid_ent, d_resid_rel, d_h, d_t, d_r, n_pos, n_neg, stride, denom, g_c.rec, g_c.dst,
+                            krel, d_loss, stream, d_resid_ent != nullptr && d_resid_rel != nullptr, rec2);
+    if (rc) return rc;
     FuseArgs fold = FuseArgs();
     if (krel > 1) { fold.fold_E = (int)m->ent_total; fold.fold_R = (int)m->rel_total; }
-    const int rpb = (rows + NB - 1) / NB;
+    if (fused) {
+        int L, C;
+        transe_team_shape(D, L, C);
+        const int cap = engine().counts_fused_cap > 0 ? std::min(engine().counts_fused_cap, 3 * L) : 3 * L;
+        const int64_t max_chunks = 4 * (M / cap + 1) + NB + 16;
+        if (max_chunks > g_c.chunks_cap) {
+            if ((rc = regrow(g_c.chunks, (size_t)max_chunks, "fused step chunk table"))) return rc;
+            g_c.chunks_cap = max_chunks;
+        }
+        if (!g_c.n_chunks) {
+            if ((rc = regrow(g_c.n_chunks, 1, "fused step chunk counter"))) return rc;
+            if ((rc = hip_check(hipMemset(g_c.n_chunks, 0, sizeof(int32_t)), "zero chunk counter"))) return rc;
+        }
+        if (m->ent_total > g_c.row_state_cap) {
+            if ((rc = regrow(g_c.row_state, (size_t)m->ent_total, "fused step row plan"))) return rc;
+            g_c.row_state_cap = m->ent_total;
+        }
+        const int n_tiles = (int)((M + BTILE - 1) / BTILE);
+        if (!g_c.bucket_start) {
+            if ((rc = regrow(g_c.bucket_start, NB + 2, "counts bucket_start"))) return rc;
+            if ((rc = regrow(g_c.tile_hist, 2 * (NB + 2), "counts bucket totals/cursors"))) return rc;
+            if ((rc = hip_check(hipMemset(g_c.tile_hist, 0, sizeof(int32_t) * 2 * (NB + 2)), "zero bucket totals"))) return rc;
+        }
+        int32_t *totals = g_c.tile_hist, *cursor = g_c.tile_hist + (NB + 2);
+        int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
+        SegPlan plan;
+        plan.chunks = g_c.chunks; plan.n_chunks = g_c.n_chunks; plan.row_state = g_c.row_state; plan.E = (int)m->ent_total; plan.cap = cap;
+        hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals, g_c.n_chunks);
+        launch_bkt_scatter(n_tiles, (int)M, rpb, totals, cursor, pairs, stream);
+        hipLaunchKernelGGL(bkt_sort_kernel<true>, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
+                           g_c.dst_sorted, g_c.ids_sorted, totals, cursor, plan);
+        const long long all_rows = m->ent_total + m->rel_total;
+        SegApplyArgs sa = {};
+        sa.rec = g_c.rec; sa.rec2 = rec2; sa.keys = g_c.dst_sorted; sa.ids = g_c.ids_sorted; sa.chunks = g_c.chunks; sa.n_chunks = g_c.n_chunks;
+        sa.n8 = 3 * (long long)n_pos; sa.RD = (int)rd; sa.S = d_counts; sa.fold_R = (int)m->rel_total;
+        ApplyArgs &a = sa.ap;
+        a.p = fo->p[0]; a.p2 = fo->p[1]; a.resid = d_resid_ent; a.resid2 = d_resid_rel;
+        if (fo->adam) { a.m = fo->m[0]; a.m2 = fo->m[1]; a.v = fo->v[0]; a.v2 = fo->v[1]; }
+        a.S = d_counts; a.rows = all_rows; a.row_lo = 0; a.E = m->ent_total; a.D = D;
+        a.unit = 1.0f / (float)denom; a.lr = fo->lr; a.b1 = fo->b1; a.b2 = fo->b2; a.eps = fo->eps; a.adam = fo->adam;
+        a.row_state = g_c.row_state;
+        {
+            Engine &e = engine();     // (as kge_transe_apply_counts_range: the two kernels together rewrite every row's 1/|row| entry)
+            const bool keeps = e.inv_carry && e.inv_valid && e.inv_norm && e.inv_for_ent == fo->p[0] && e.inv_for_rel == fo->p[1] && e.inv_cap >= all_rows;
+            if (keeps) a.inv_out = e.inv_norm;
+            else tables_written();
+        }
+#define KGE_SEGAPPLY(LL, CC)                                                                                          \
+    {                                                                                                                 \
+        const long long nb = (max_chunks + (256 / LL) - 1) / (256 / LL);                                              \
+        hipLaunchKernelGGL((segapply_kernel<LL, CC>), dim3((unsigned)nb), dim3(256), 0, stream, sa);                   \
+        long long nb2 = (all_rows + (256 / LL) - 1) / (256 / LL);                                                     \
+        if (nb2 > 8192) nb2 = 8192;                                                                                   \
+        hipLaunchKernelGGL((apply_counts_kernel<LL, CC, false>), dim3((unsigned)nb2), dim3(256), 0, stream, a);        \
+    }
+        if (D <= 64) KGE_SEGAPPLY(16, 4) else if (D <= 128) KGE_SEGAPPLY(32, 4) else if (D <= 256) KGE_SEGAPPLY(64, 4)
+        else if (D <= 512) KGE_SEGAPPLY(64, 8) else KGE_SEGAPPLY(64, 16)
+#undef KGE_SEGAPPLY
+        fo->done = true;
+        return hip_check(hipGetLastError(), "fused counts step launch");
+    }
     if (rpb <= 8192 && !engine().counts_force_sort) {
         // ---- two-level counting sort (hand-written) + segmented sum: row spaces up to NB*8192 rows ----
         const int n_tiles = (int)((M + BTILE - 1) / BTILE);
@@ -1158,8 +1501,8 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
         int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
         hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals);
         launch_bkt_scatter(n_tiles, (int)M, rpb, totals, cursor, pairs, stream);
-        hipLaunchKernelGGL(bkt_sort_kernel, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
-                           g_c.dst_sorted, g_c.ids_sorted, totals, cursor);
+        hipLaunchKernelGGL(bkt_sort_kernel<false>, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
+                           g_c.dst_sorted, g_c.ids_sorted, totals, cursor, SegPlan());
         const int32_t *n_valid_p = g_c.bucket_start + NB;   // start of the trash bucket == number of live records
 #define KGE_SEG2(LL, CC)                                                                                              \
     {                                                                                                                 \
@@ -1195,6 +1538,36 @@ int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const
     KGE_SHAPE_DISPATCH(D, KGE_SEG)
 #undef KGE_SEG
     return hip_check(hipGetLastError(), "counts reduce launch");
+}
+
+extern "C" {
+
+int kge_transe_forward_counts(const kge_model_desc *m, const float *d_ent, const float *d_rel, const int32_t *d_h,
+                              const int32_t *d_t, const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom,
+                              int32_t *d_counts, float *d_resid_ent, float *d_resid_rel, float *d_loss, void *stream_) {
+    return forward_counts_impl(m, d_ent, d_rel, d_h, d_t, d_r, n_pos, n_neg, stride, denom, d_counts, d_resid_ent, d_resid_rel, d_loss,
+                               stream_, nullptr);
+}
+
+int kge_transe_train_step_counts(const kge_model_desc *m, float *const d_p[2], float *const d_m[2], float *const d_v[2], const int32_t *d_h,
+                                 const int32_t *d_t, const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom, int32_t *d_counts,
+                                 float *const d_resid[2], int32_t sampler_shaped, int32_t adam, float lr, float beta1, float beta2, float eps,
+                                 float *d_loss, void *stream_) {
+    if (!m || !d_p || !d_p[0] || !d_p[1] || !d_counts || !d_resid || !d_resid[0] || !d_resid[1] || denom <= 0)
+        return fail(KGE_ERR_BAD_ARG, "kge_transe_train_step_counts: bad arguments");
+    if (adam && (!d_m || !d_v || !d_m[0] || !d_m[1] || !d_v[0] || !d_v[1]))
+        return fail(KGE_ERR_BAD_ARG, "kge_transe_train_step_counts: Adam needs the moment tables");
+    FusedOpt fo;
+    fo.p[0] = d_p[0]; fo.p[1] = d_p[1];
+    fo.m[0] = adam ? d_m[0] : nullptr; fo.m[1] = adam ? d_m[1] : nullptr; fo.v[0] = adam ? d_v[0] : nullptr; fo.v[1] = adam ? d_v[1] : nullptr;
+    fo.adam = adam; fo.lr = lr; fo.b1 = beta1; fo.b2 = beta2; fo.eps = eps;
+    const bool fed = !sampler_shaped;     // a hand-made batch: deferral bookkeeping + the exact fp32 pass into the residual tables
+    int rc = forward_counts_impl(m, d_p[0], d_p[1], d_h, d_t, d_r, n_pos, n_neg, stride, denom, d_counts, fed ? d_resid[0] : nullptr,
+                                 fed ? d_resid[1] : nullptr, d_loss, stream_, &fo);
+    if (rc || fo.done) return rc;
+    // (this width / table size has no fused kernels: the image is complete, the apply kernel finishes the step)
+    return kge_transe_apply_counts_range(m, d_p, d_m, d_v, d_counts, d_resid, 0, m->ent_total + m->rel_total, denom, adam, lr, beta1, beta2,
+                                         eps, stream_);
 }
 
 INT kge_transe_record_dwords(const kge_model_desc *m) {
