@@ -87,6 +87,7 @@ struct Engine {
     int persist_threads = 512;  // threads per workgroup of the persistent launch (512, or 1024: spills at its 128-register cap, measured slower)
     int counts_force_sort = 0;  // test hook: take the sort+segsum reduction even for small tables
     int counts_fused = 1;       // kge_transe_train_step_counts: 1 = segmented sum and optimizer in one kernel (segapply_kernel); 0 = segsum + apply kernels
+    int counts_fused_diag = 0;  // measurement hook, see SegApplyArgs::diag
     int counts_fused_cap = 0;   // test hook: rows of more than this many records go through the count image (0 = the kernel's capacity, 3 x team width)
 };
 

@@ -436,7 +436,8 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
                         } else {
                             store_record<L, Q>(a, lane, m, rec);
                         }
-                        if (lane == kk + u) my_dst = code[u] == 2 ? rel_row0 + row[u] : row[u];
+                        // (REC2: the destination key is 2 * row + kind -- a row's int8 records and its 2-bit records form two lists)
+                        if (lane == kk + u) my_dst = REC2 ? 2 * (code[u] == 2 ? rel_row0 + row[u] : row[u]) + 1 : (code[u] == 2 ? rel_row0 + row[u] : row[u]);
                     }
                 }
             }
@@ -458,9 +459,10 @@ __global__ __launch_bounds__(256, WPE) void transe_emit_vec_kernel(FbArgs a) {
             store_record<L, Q>(a, lane, 2 * a.n_pos + b, rr);
         }
         if (lane == 0) {
-            a.dst[b] = cnt > 0 ? (int32_t)h : -1;
-            a.dst[a.n_pos + b] = cnt > 0 ? (int32_t)t : -1;
-            a.dst[2 * a.n_pos + b] = cnt > 0 ? (int32_t)(rel_row0 + r) : -1;
+            constexpr int KM = REC2 ? 2 : 1;
+            a.dst[b] = cnt > 0 ? (int32_t)(KM * h) : -1;
+            a.dst[a.n_pos + b] = cnt > 0 ? (int32_t)(KM * t) : -1;
+            a.dst[2 * a.n_pos + b] = cnt > 0 ? (int32_t)(KM * (rel_row0 + r)) : -1;
         }
     }
     finish_loss<TEAMS>(a, red, lsum, lane, team_in_block);

@@ -28,6 +28,8 @@ struct FbArgs {
     // bytes per record), element j of the lane's four as the 2-bit field (sign + 1) in {0, 1, 2} at bits 2j.  A negative's
     // gradient w.r.t. its one new normalised vector is +-sign(e): two bits per element say it all, and the negatives are 25 of
     // the 28 records of a bench group (64 B instead of 256 B each).  Slots 0..2 (sums of up to 2 n signs) stay int8 in `rec`.
+    // In this mode the destination KEYS are 2 * row (int8 records) and 2 * row + 1 (2-bit records): ordered by key, a row's
+    // records come as two homogeneous lists and the reducer needs no test per record.
     uint8_t *rec2;
     int ent_total, rel_total, krel;
     // indirection for the deferred groups of the sign-count path: when group_list != nullptr the

@@ -55,11 +55,11 @@ struct CtWork {
     int32_t *bflag = nullptr;
     int64_t bflag_cap = 0;
     // fused single-process step: the plan of segapply_kernel
-    int4 *chunks = nullptr;
-    int64_t chunks_cap = 0;
-    int32_t *n_chunks = nullptr;
-    uint8_t *row_state = nullptr;
-    int64_t row_state_cap = 0;
+    int4 *pieces = nullptr;
+    int64_t pieces_cap = 0;
+    int32_t *n_pieces = nullptr;
+    int2 *row_span = nullptr;
+    int64_t row_span_cap = 0;
 };
 CtWork g_c;
 
@@ -118,7 +118,6 @@ __global__ void count_valid_kernel(const int32_t *__restrict__ sorted, int M, in
 }
 
 constexpr int CHUNK = 64;
-constexpr uint8_t kRowEmpty = 0, kRowDirect = 1, kRowImage = 2;   // fused step: per-row plan (bkt_sort_kernel<true>)
 
 // value held by lane `i` of the calling lane's L-lane team (i a compile-time constant where it matters: a full wave reads it
 // into an SGPR with v_readlane, narrower teams go through ds_bpermute)
@@ -453,17 +452,17 @@ static void launch_bkt_scatter(int n_tiles, int M, int rpb, int32_t *totals, int
 // that the whole list is row-sorted and the register-accumulating segsum_kernel can consume it.
 // (An LDS-image reduction with ds_add per element was tried first: correct, but bound by the LDS
 // atomic rate -- 3.8 M wave-level ds_add per step -- at 230 us; registers + sorted runs take ~60.)
-// PLAN (the fused single-process step): the bucket also plans the work of segapply_kernel for its rows --
-//   row_state[row] for every ENTITY row of the bucket: kRowEmpty (no record), kRowDirect (all its records lie in ONE chunk:
-//   summed in registers and updated right there), kRowImage (more than `cap` records: summed into the count image by pieces);
-//   chunks: (first, end) positions in the sorted list + flag; a chunk holds WHOLE rows of at most `cap` records together (greedy, in
-//   row order), or -- flag 1 -- one piece of at most `cap` records of a longer row.  Chunk slots are taken from one global counter,
-//   one atomic per bucket.
+// PLAN (the fused single-process step; keys are 2 * row + kind, FbArgs::rec2): the bucket also writes where each of its keys
+// lies in the sorted list -- row_span[key] = (first position, number of records), for EVERY key of the bucket, empty ones
+// included -- which is all segapply_kernel needs to give every row a team of its own (a row = two adjacent keys = two
+// homogeneous record lists).  A row with a list of more than `cap` records is cut into pieces of at most `cap` records of one
+// list (slots from one global counter, zeroed by bkt_hist_kernel), each piece a team of its own that adds into the count image.
+// rpb is even, so the two keys of a row lie in the same bucket.
 struct SegPlan {
-    int4 *chunks;          // [max_chunks]  (first, end, flag, 0)
-    int32_t *n_chunks;     // zeroed by the apply kernel that ends the step
-    uint8_t *row_state;    // [E]
-    int E, cap;
+    int2 *row_span;        // [2 * virtual rows]
+    int4 *pieces;          // [max_pieces]  (key, first position, records, 0)
+    int32_t *n_pieces;
+    int cap;
 };
 
 template <bool PLAN>
@@ -483,7 +482,7 @@ __global__ __launch_bounds__(256) void bkt_sort_kernel(const int2 *__restrict__ 
     for (int i = threadIdx.x; i < rpb; i += 256) lds_h[i] = 0;
     if (end == start) {
         if constexpr (PLAN)
-            for (int i = threadIdx.x; i < rpb; i += 256) if (row0 + i < plan.E) plan.row_state[row0 + i] = kRowEmpty;
+            for (int i = threadIdx.x; i < rpb; i += 256) if (row0 + i < rows) plan.row_span[row0 + i] = make_int2(start, 0);
         return;
     }
     // the first 256*PC pairs of the bucket (all of it, normally) are read ONCE, into registers, for both passes
@@ -537,40 +536,19 @@ __global__ __launch_bounds__(256) void bkt_sort_kernel(const int2 *__restrict__ 
         out_ids[pos] = q.x;
     }
     if constexpr (PLAN) {
-        __syncthreads();     // lds_h[i] is now the END offset of row i inside the bucket (= the start of row i + 1)
+        __syncthreads();     // lds_h[i] is now the END offset of key i inside the bucket (= the start of key i + 1)
         const int cap = plan.cap;
         for (int i = threadIdx.x; i < rpb; i += 256) {
-            const int row = row0 + i;
-            if (row < plan.E && row < rows) {
-                const int c = lds_h[i] - (i ? lds_h[i - 1] : 0);
-                plan.row_state[row] = c == 0 ? kRowEmpty : (c > cap ? kRowImage : kRowDirect);
-            }
-        }
-        if (threadIdx.x == 0) {
-            // two passes over the bucket's rows by one thread (a few dozen rows): count the chunks, take that many slots with ONE
-            // atomic, write them
-            int base = 0;
-            for (int pass = 0; pass < 2; pass++) {
-                int n = 0, cur_first = 0, cur_n = 0;
-                auto put = [&](int first, int last, int flag) {
-                    if (pass) plan.chunks[base + n] = make_int4(start + first, start + last, flag, 0);
-                    n++;
-                };
-                const int r_hi = min(rpb, rows - row0);
-                for (int i = 0; i < r_hi; i++) {
-                    const int lo = i ? lds_h[i - 1] : 0, c = lds_h[i] - lo;
-                    if (c == 0) continue;
-                    if (c > cap) {
-                        if (cur_n) { put(cur_first, cur_first + cur_n, 0); cur_n = 0; }
-                        for (int off = 0; off < c; off += cap) put(lo + off, lo + min(off + cap, c), 1);
-                    } else {
-                        if (cur_n + c > cap) { put(cur_first, cur_first + cur_n, 0); cur_n = 0; }
-                        if (cur_n == 0) cur_first = lo;
-                        cur_n += c;
-                    }
-                }
-                if (cur_n) put(cur_first, cur_first + cur_n, 0);
-                if (pass == 0) base = n ? atomicAdd(plan.n_chunks, n) : 0;
+            const int key = row0 + i;
+            if (key >= rows) break;
+            const int lo = i ? lds_h[i - 1] : 0, c = lds_h[i] - lo;
+            plan.row_span[key] = make_int2(start + lo, c);
+            const int io = i ^ 1;                                         // the row's other list (same bucket: rpb is even)
+            const int co = lds_h[io] - (io ? lds_h[io - 1] : 0);
+            if (c > 0 && (c > cap || co > cap)) {                         // a long row: BOTH its lists go to the image, in pieces
+                const int np = (c + cap - 1) / cap;
+                const int base = atomicAdd(plan.n_pieces, np);
+                for (int q = 0; q < np; q++) plan.pieces[base + q] = make_int4(key, start + lo + q * cap, min(cap, c - q * cap), 0);
             }
         }
     }
@@ -1076,7 +1054,8 @@ struct ApplyArgs {
     float *p2, *m2, *v2, *resid2;
     long long E;
     long long row_lo;   // dense form on a row RANGE [row_lo, rows): S points at the image of row_lo (a rank's reduce-scattered chunk)
-    const uint8_t *row_state;   // fused step: per ENTITY row, what segapply_kernel did with it (kRowDirect rows are skipped here); else null
+    const int2 *row_span;       // fused step: (first position, records) per key 2 * row + kind; entity rows whose two lists hold at most
+    int span_cap;               // span_cap records each were updated by segapply_kernel itself and are skipped here; null otherwise
     float *inv_out;     // dense full-table form: the emit kernel's 1/|row| table ([E + R], row-space index), refreshed for every row rewritten
                         // here so that the next step needs no pre-pass
 };
@@ -1160,7 +1139,7 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
     for (long long i = a.row_lo + (long long)blockIdx.x * TEAMS + threadIdx.x / L; i < n_rows; i += (long long)gridDim.x * TEAMS) {
         long long row = SPARSE ? (long long)a.row_list[i] : i;
         // behind the fused segmented-sum-and-apply kernel: the entity rows it has already updated from registers are skipped
-        if (!SPARSE && a.row_state && row < a.E && a.row_state[row] == kRowDirect) continue;
+        if (!SPARSE && a.row_span && row < a.E && a.row_span[2 * row].y <= a.span_cap && a.row_span[2 * row + 1].y <= a.span_cap) continue;
         float *table = a.p, *mt = a.m, *vt = a.v, *rt = a.resid;
         if (row >= a.E) { row -= a.E; table = a.p2; mt = a.m2; vt = a.v2; rt = a.resid2; }
         int32_t *Sp = a.S + (i - a.row_lo) * a.D;
@@ -1188,50 +1167,45 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
 // Fused segmented sum + optimizer step (single process, dense tables): stages 2b and 3 in one kernel, without the count image
 // for the rows whose records one team can hold.
 //
-// One team per CHUNK of the plan bkt_sort_kernel<true> made: whole rows of at most cap records together, or one piece of a longer
-// row.  The team sums each row's records in registers (natural layout: lane l holds elements 4l..4l+3) -- int8 records through
-// v_dot4 with a one-hot selector (one instruction per element), the negatives' 2-bit records (FbArgs::rec2) by spreading the
-// lane's byte into four byte-wide fields and adding them packed (five instructions per record, unpacked every <= 127 records) --
-// and at the end of a row
-//   * an entity row that lies wholly in this chunk is UPDATED here: its parameter / moment rows were requested when its first
-//     record was seen, the sums are turned into the team layout through LDS, and apply_row_update does exactly what the apply
-//     kernel would have done with the same sums (bit-identical to the two-kernel path, which the data-parallel step keeps);
-//   * a piece of a longer row and every relation row (virtual copies fold onto one row, and a hub relation has thousands of
-//     records) is added into the int32 count image with atomics; apply_counts_kernel then runs over those rows and over the rows
-//     without any record (TF1 Adam moves them too), skipping the rows updated here (row_state).
-// What this saves against segsum_kernel + apply_counts_kernel: the image traffic of the direct rows (written, read, re-zeroed:
-// 35 MB of a bench step), nearly all boundary atomics (a chunk of 64 sorted records there ends inside a row almost always), and
-// three quarters of the record bytes.
+// ONE TEAM PER ROW of the virtual row space (entities, then the virtual copies of the relation rows), told by bkt_sort_kernel<true>
+// where the row's records lie in the sorted list (row_span).  The team requests the row's parameter / moment rows, sums the
+// row's records in registers (natural layout: lane l holds elements 4l..4l+3) -- int8 records through v_dot4 with a one-hot
+// selector (one instruction per element), the negatives' 2-bit records (FbArgs::rec2) by spreading the lane's byte into four
+// byte-wide fields and adding them packed (five instructions per record, unpacked every <= 127 records) -- turns the sums into
+// the team layout through LDS and calls apply_row_update: exactly what the apply kernel would have done with the same sums
+// (bit-identical to the two-kernel path, which the data-parallel step keeps).  TF1 Adam moves rows without records too: their
+// teams do that.  With a full wave per team (widths 132..1024) everything about WHICH records is wave-uniform: positions, record
+// ids and base addresses live in scalar registers (scalar loads, scalar address arithmetic), the vector unit only adds.
+//   * A row of more than `cap` records (hub entities) is cut into pieces by the planner; the pieces are further teams of this
+//     launch that add into the int32 count image with atomics, and so does every relation row (virtual copies fold onto one row;
+//     a hub relation has thousands of records).  apply_counts_kernel then runs over those rows only (row_span tells it which).
+// What this saves against segsum_kernel + apply_counts_kernel: the image traffic of nearly all rows (written, read, re-zeroed:
+// 35 MB of a bench step), the boundary atomics (a chunk of 64 sorted records there ends inside a row almost always), the key
+// comparisons per record, and three quarters of the record bytes.
 // ---------------------------------------------------------------------------------------------
 struct SegApplyArgs {
-    const uint32_t *rec;     // int8 records [n8][RD dwords]
-    const uint8_t *rec2;     // 2-bit records [*][RD bytes], record id - n8
-    const int32_t *keys, *ids;
-    const int4 *chunks;
-    const int32_t *n_chunks;
-    long long n8;
-    int RD;
+    const uint32_t *rec;     // int8 records [n8][RD dwords]; the 2-bit records [*][RD bytes] follow at byte offset rec2_off
+    const int32_t *ids;      // record ids in key order
+    const int2 *row_span;    // [2 * n_rows_v] (first position, records) per key 2 * row + kind
+    const int4 *pieces;      // (key, first position, records, 0)
+    const int32_t *n_pieces;
+    unsigned rec2_off;       // (all record bytes together stay below 4 GB: offsets are 32-bit, the host checks)
+    int n8;                  // ids below this are int8 records
+    int m_last;              // last valid position of `ids`
+    int n_rows_v;            // virtual rows: E + krel * R
+    int RD, cap;
     int32_t *S;              // count image
-    int fold_R;              // relations: key >= ap.E is copy (key - E) / fold_R of relation (key - E) % fold_R
+    int fold_R;              // relations: row >= ap.E is copy (row - E) / fold_R of relation (row - E) % fold_R
+    int diag;                // measurement hook (option "counts_fused_diag"): 1 = no record loops, 2 = no row update (WRONG results)
     ApplyArgs ap;
 };
-
-// entry i (wave-uniform, dynamic) of a list held as a[j] = entry (lane + L*j)
-template <int L, int J>
-__device__ __forceinline__ int entry_dyn(const int (&a)[J], int i) {
-    int v = a[0];
-#pragma unroll
-    for (int j = 1; j < J; j++) v = (i / L == j) ? a[j] : v;
-    if constexpr (L == 64) return __builtin_amdgcn_readlane(v, i % L);
-    else return __shfl(v, i % L, L);
-}
 
 template <int L, int C>
 __global__ __launch_bounds__(256) void segapply_kernel(SegApplyArgs sa) {
     constexpr int TEAMS = 256 / L;
     constexpr int Q = C / 4;
-    constexpr int J = 3;              // a chunk holds at most J*L records (the planner's cap)
     constexpr int U = 16;             // records in flight per team
+    constexpr int J = 128 / L > 0 ? (128 / L > 4 ? 4 : 128 / L) : 1;   // id registers per list: a list holds at most J * L records (the planner's cap)
     static_assert(C % 4 == 0, "natural record layout: four elements per lane and chunk");
     __shared__ int32_t stage_all[256 * C];
     int32_t *stage = stage_all + (threadIdx.x / L) * (L * C);
@@ -1240,121 +1214,138 @@ __global__ __launch_bounds__(256) void segapply_kernel(SegApplyArgs sa) {
     tm.D = sa.ap.D;
     const int lane = tm.lane;
     const ApplyArgs &ap = sa.ap;
-    const long long team = (long long)blockIdx.x * TEAMS + threadIdx.x / L;
-    if (team >= sa.n_chunks[0]) return;
-    const int4 ch = sa.chunks[team];
-    const int start = ch.x, n = ch.y - ch.x;
-    const bool piece = ch.z != 0;
-    int kl[J], idl[J];
+    // a full wave per team: the team index is wave-uniform (told to the compiler, so that what follows is scalar code)
+    auto uni = [](int v) { if constexpr (L == 64) return __builtin_amdgcn_readfirstlane(v); else return v; };
+    const int team = uni((int)(blockIdx.x * TEAMS + threadIdx.x / L));
+    int row, start8, n8, start2, n2;
+    bool piece = false;
+    // the longest-running teams first: the pieces of long rows (cap records each), then the relation rows (hundreds of records on a
+    // graph with few relations), then the entity rows -- with the pieces at the END of the grid the launch had a tail of teams that
+    // started last and ran longest (measured: 2 waves per SIMD resident on average)
+    const int np = uni(sa.n_pieces[0]);
+    if (team < np) {
+        const int4 pc = sa.pieces[team];
+        const int key = uni(pc.x);
+        row = key >> 1;
+        start8 = start2 = uni(pc.y);
+        n8 = (key & 1) ? 0 : uni(pc.z);
+        n2 = (key & 1) ? uni(pc.z) : 0;
+        piece = true;
+    } else {
+        const int r = team - np, n_rel_v = sa.n_rows_v - (int)ap.E;
+        if (r >= sa.n_rows_v) return;
+        row = r < n_rel_v ? (int)ap.E + r : r - n_rel_v;
+        const int4 sp = *reinterpret_cast<const int4 *>(sa.row_span + 2 * row);     // both lists of the row
+        start8 = uni(sp.x); n8 = uni(sp.y); start2 = uni(sp.z); n2 = uni(sp.w);
+        if (n8 > sa.cap || n2 > sa.cap) return;                                      // a long row: its pieces are teams of their own
+        if (n8 + n2 == 0 && (row >= ap.E || (!ap.adam && !ap.resid))) return;        // nothing to do (TF1 Adam moves record-less rows too)
+    }
+    const bool direct = !piece && row < ap.E;
+    float x[C], mo[C], vo[C];
+    if (direct) {                      // requested now, needed after the records
+        tm.load(ap.p, row, x);
+        if (ap.adam) { tm.load(ap.m, row, mo); tm.load(ap.v, row, vo); }
+    }
+    if (sa.diag & 1) n8 = n2 = 0;
+    // The record ids of both lists, requested at once with the parameter rows (lane l holds ids l, l + L, ... of a list), and
+    // turned into 32-bit BYTE OFFSETS of the records right here, in the lanes: per record the loops below then spend one
+    // v_readlane (the offset, into a scalar register), one add and the load -- no scalar multiply, no test, no branch.  (The
+    // first version computed every record's address with ~14 scalar instructions and two branches: the kernel was bound by the
+    // scalar unit, 75 us of instruction issue with the loads removed.)
+    unsigned o8[J], o2[J];
 #pragma unroll
     for (int j = 0; j < J; j++) {
-        const int i = min(lane + L * j, n - 1);
-        kl[j] = sa.keys[start + i];
-        idl[j] = sa.ids[start + i];
+        const int i8 = sa.ids[min(start8 + min(lane + L * j, max(n8 - 1, 0)), sa.m_last)];     // (an empty list at the very end: stay inside the array)
+        const int i2 = sa.ids[min(start2 + min(lane + L * j, max(n2 - 1, 0)), sa.m_last)];
+        o8[j] = (unsigned)i8 * (unsigned)(4 * sa.RD);
+        o2[j] = sa.rec2_off + (unsigned)(i2 - sa.n8) * (unsigned)sa.RD;
     }
     int acc[C];
-    uint32_t pk[Q];
 #pragma unroll
     for (int c = 0; c < C; c++) acc[c] = 0;
+    const char *recb = reinterpret_cast<const char *>(sa.rec);
+    auto offset_at = [&](const unsigned (&o)[J], int i) -> unsigned {     // entry i of a list of offsets (i is uniform across the team)
+        unsigned v = o[0];
 #pragma unroll
-    for (int q = 0; q < Q; q++) pk[q] = 0u;
-    int n2 = 0;                       // 2-bit records added into pk since it was last unpacked
-    float x[C], mo[C], vo[C];
-    auto direct = [&](int key) { return !piece && key < ap.E; };
-    auto request = [&](int key) {     // the row's parameter / moment rows, asked for when its first record is seen
-        if (direct(key)) {
-            tm.load(ap.p, key, x);
-            if (ap.adam) { tm.load(ap.m, key, mo); tm.load(ap.v, key, vo); }
-        }
+        for (int j = 1; j < J; j++) v = (i / L == j) ? o[j] : v;
+        if constexpr (L == 64) return (unsigned)__builtin_amdgcn_readlane((int)v, i % L); else return (unsigned)__shfl((int)v, i % L, L);
     };
-    auto unpack = [&]() {             // pk fields hold sum (sign + 1) over n2 records
-#pragma unroll
-        for (int q = 0; q < Q; q++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[4 * q + j] += (int)((pk[q] >> (8 * j)) & 0xFFu) - n2;
-            pk[q] = 0u;
-        }
-        n2 = 0;
-    };
-    auto finish = [&](int key) {
-        unpack();
-#pragma unroll
-        for (int q = 0; q < Q; q++)
-            *reinterpret_cast<int4 *>(stage + 4 * (lane + L * q)) = make_int4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-        int si[C];
-#pragma unroll
-        for (int c = 0; c < C; c++) { const int e = lane + L * c; si[c] = e < ap.D ? stage[e] : 0; acc[c] = 0; }
-        if (direct(key)) {
-            float sf[C], rs[C];
-            float *rp = ap.resid ? ap.resid + (long long)key * ap.D : nullptr;
-#pragma unroll
-            for (int c = 0; c < C; c++) { const int e = lane + L * c; sf[c] = (float)si[c]; rs[c] = (rp && e < ap.D) ? rp[e] : 0.f; }
-            apply_row_update<L, C, false>(tm, ap, ap.p, ap.m, ap.v, key, key, sf, rs, x, mo, vo, true, nullptr, rp);
-        } else {
-            const long long row = key < ap.E ? key : ap.E + (key - ap.E) % sa.fold_R;
-            int32_t *p = sa.S + row * ap.D;
-#pragma unroll
-            for (int c = 0; c < C; c++) { const int e = lane + L * c; if (e < ap.D && si[c] != 0) atomicAdd(p + e, si[c]); }
-        }
-    };
-    int cur = entry_dyn<L, J>(kl, 0);
-    request(cur);
-    for (int i0 = 0; i0 < n; i0 += U) {
-        int k[U];
+    // ---- list 1: int8 records (the positives' h / t / r slots), lane l reads dword l (+ L q); v_dot4 with a one-hot selector adds
+    // one element per instruction
+    for (int i0 = 0; i0 < n8; i0 += U) {
         uint32_t w[U][Q];
-        unsigned two = 0;                          // bit u: record u of the batch is a 2-bit record
-        const int nb = min(U, n - i0);             // records of this batch
+        const int nb = min(U, n8 - i0);
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int i = min(i0 + u, n - 1);      // entries past n repeat the last record (never consumed): loads stay unconditional
-            k[u] = entry_dyn<L, J>(kl, i);
-            const long long id = entry_dyn<L, J>(idl, i);
-            if (id >= sa.n8) {
-                two |= 1u << u;
-                const uint8_t *p = sa.rec2 + (id - sa.n8) * sa.RD;
+            if (u < nb) {
+                const char *p = recb + offset_at(o8, i0 + u);
 #pragma unroll
-                for (int q = 0; q < Q; q++) w[u][q] = p[lane + L * q];
-            } else {
-                const uint32_t *p = sa.rec + id * sa.RD;
-#pragma unroll
-                for (int q = 0; q < Q; q++) w[u][q] = p[lane + L * q];
+                for (int q = 0; q < Q; q++) w[u][q] = *reinterpret_cast<const uint32_t *>(p + 4 * (lane + L * q));
             }
         }
-        // consume the batch run by run: ONE copy of the accumulate block and ONE of the row finish in the code (the finish inlined at
-        // every record position made the kernel spill); the records of the current row are those from u0 on whose key equals `cur`
-        int u0 = 0;
-        while (u0 < nb) {
-            int stop = nb, next = cur;             // first position >= u0 of another row, and that row
 #pragma unroll
-            for (int u = U - 1; u >= 0; u--)
-                if (u >= u0 && u < nb && k[u] != cur) { stop = u; next = k[u]; }
+        for (int u = 0; u < U; u++) {
+            if (u < nb) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (u < u0 || u >= stop) continue;
-                if ((two >> u) & 1u) {
+                for (int q = 0; q < Q; q++) {
 #pragma unroll
-                    for (int q = 0; q < Q; q++) {
-                        const uint32_t b = w[u][q];
-                        pk[q] += (b | (b << 6) | (b << 12) | (b << 18)) & 0x03030303u;
-                    }
-                    if (++n2 == 127) unpack();
-                } else {
-#pragma unroll
-                    for (int q = 0; q < Q; q++) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++) acc[4 * q + j] = __builtin_amdgcn_sdot4((int)w[u][q], 1 << (8 * j), acc[4 * q + j], false);
-                    }
+                    for (int j = 0; j < 4; j++) acc[4 * q + j] = __builtin_amdgcn_sdot4((int)w[u][q], 1 << (8 * j), acc[4 * q + j], false);
                 }
-            }
-            u0 = stop;
-            if (u0 < nb) {
-                finish(cur);
-                cur = next;
-                request(cur);
             }
         }
     }
-    finish(cur);
+    // ---- list 2: the negatives' 2-bit records, lane l reads BYTE l (+ L q): four fields (sign + 1); spread into four byte-wide
+    // fields and added packed; a list holds at most 128 records (cap), so a field stays below 256 and is unpacked once
+    uint32_t pk[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) pk[q] = 0u;
+    for (int i0 = 0; i0 < n2; i0 += U) {
+        uint32_t w[U][Q];
+        const int nb = min(U, n2 - i0);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (u < nb) {
+                const uint8_t *p = reinterpret_cast<const uint8_t *>(recb) + offset_at(o2, i0 + u);
+#pragma unroll
+                for (int q = 0; q < Q; q++) w[u][q] = p[lane + L * q];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (u < nb) {
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    const uint32_t b = w[u][q];
+                    pk[q] += (b | (b << 6) | (b << 12) | (b << 18)) & 0x03030303u;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[4 * q + j] += (int)((pk[q] >> (8 * j)) & 0xFFu) - n2;      // fields hold sum (sign + 1)
+    }
+    // natural -> team layout through this team's LDS patch (one wave: its LDS operations complete in order)
+#pragma unroll
+    for (int q = 0; q < Q; q++)
+        *reinterpret_cast<int4 *>(stage + 4 * (lane + L * q)) = make_int4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    int si[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) { const int e = lane + L * c; si[c] = e < ap.D ? stage[e] : 0; }
+    if (sa.diag & 2) return;
+    if (direct) {
+        float sf[C], rs[C];
+        float *rp = ap.resid ? ap.resid + (long long)row * ap.D : nullptr;
+#pragma unroll
+        for (int c = 0; c < C; c++) { const int e = lane + L * c; sf[c] = (float)si[c]; rs[c] = (rp && e < ap.D) ? rp[e] : 0.f; }
+        apply_row_update<L, C, false>(tm, ap, ap.p, ap.m, ap.v, row, row, sf, rs, x, mo, vo, true, nullptr, rp);
+    } else {
+        const long long irow = row < ap.E ? row : ap.E + (row - ap.E) % sa.fold_R;
+        int32_t *p = sa.S + irow * ap.D;
+#pragma unroll
+        for (int c = 0; c < C; c++) { const int e = lane + L * c; if (e < ap.D && si[c] != 0) atomicAdd(p + e, si[c]); }
+    }
 }
 
 #define KGE_SHAPE_DISPATCH(D, CALL)                                      \
@@ -1419,9 +1410,11 @@ static int forward_counts_impl(const kge_model_desc *m, const float *d_ent, cons
     const int D = m->ent_dim;
     const bool nat = D % 4 == 0;   // the vectorised emit kernel writes records in natural element order
     const int rpb = (rows + NB - 1) / NB;
-    // the fused segmented-sum-and-apply path: natural-layout records, the bucket sort (whose buckets plan its chunks: one thread
-    // walks a bucket's rows, so buckets stay small), row ids that fit the plan
-    const bool fused = fo && nat && rpb <= 1024 && !engine().counts_force_sort && engine().counts_fused;
+    // the fused segmented-sum-and-apply path: natural-layout records, the bucket sort (over the doubled key space 2 * row + kind,
+    // whose buckets tell every row where its two record lists lie), all record bytes below 4 GB (32-bit offsets in the kernel)
+    const int rows2 = 2 * rows, rpb2 = 2 * ((rows + NB - 1) / NB);
+    const bool fused = fo && nat && rpb2 <= 4096 && !engine().counts_force_sort && engine().counts_fused &&
+                       (uint64_t)M * rd * 4 < (uint64_t(1) << 32) && rows2 < (1 << 30);
     uint8_t *rec2 = fused ? reinterpret_cast<uint8_t *>(g_c.rec + (size_t)3 * (size_t)n_pos * rd) : nullptr;
     rc = launch_transe_emit(*m, d_ent, d_rel, d_resid_ent, d_resid_rel, d_h, d_t, d_r, n_pos, n_neg, stride, denom, g_c.rec, g_c.dst,
                             krel, d_loss, stream, d_resid_ent != nullptr && d_resid_rel != nullptr, rec2);
@@ -1429,21 +1422,21 @@ static int forward_counts_impl(const kge_model_desc *m, const float *d_ent, cons
     FuseArgs fold = FuseArgs();
     if (krel > 1) { fold.fold_E = (int)m->ent_total; fold.fold_R = (int)m->rel_total; }
     if (fused) {
-        int L, C;
-        transe_team_shape(D, L, C);
-        const int cap = engine().counts_fused_cap > 0 ? std::min(engine().counts_fused_cap, 3 * L) : 3 * L;
-        const int64_t max_chunks = 4 * (M / cap + 1) + NB + 16;
-        if (max_chunks > g_c.chunks_cap) {
-            if ((rc = regrow(g_c.chunks, (size_t)max_chunks, "fused step chunk table"))) return rc;
-            g_c.chunks_cap = max_chunks;
+        int L_, C_;
+        transe_team_shape(D, L_, C_);
+        const int cap = std::min(engine().counts_fused_cap > 0 ? engine().counts_fused_cap : 64, std::min(127, 4 * L_));   // (the kernel holds min(128, 4 L) ids per list; 127: the packed 2-bit sums stay below 256)
+        const int64_t max_pieces = 3 * (M / cap + 1) + 16;     // sum of ceil(c / cap) over both lists of the rows with a list of more than cap records
+        if (max_pieces > g_c.pieces_cap) {
+            if ((rc = regrow(g_c.pieces, (size_t)max_pieces, "fused step piece table"))) return rc;
+            g_c.pieces_cap = max_pieces;
         }
-        if (!g_c.n_chunks) {
-            if ((rc = regrow(g_c.n_chunks, 1, "fused step chunk counter"))) return rc;
-            if ((rc = hip_check(hipMemset(g_c.n_chunks, 0, sizeof(int32_t)), "zero chunk counter"))) return rc;
+        if (!g_c.n_pieces) {
+            if ((rc = regrow(g_c.n_pieces, 1, "fused step piece counter"))) return rc;
+            if ((rc = hip_check(hipMemset(g_c.n_pieces, 0, sizeof(int32_t)), "zero piece counter"))) return rc;
         }
-        if (m->ent_total > g_c.row_state_cap) {
-            if ((rc = regrow(g_c.row_state, (size_t)m->ent_total, "fused step row plan"))) return rc;
-            g_c.row_state_cap = m->ent_total;
+        if (rows2 > g_c.row_span_cap) {
+            if ((rc = regrow(g_c.row_span, (size_t)rows2, "fused step row spans"))) return rc;
+            g_c.row_span_cap = rows2;
         }
         const int n_tiles = (int)((M + BTILE - 1) / BTILE);
         if (!g_c.bucket_start) {
@@ -1454,21 +1447,22 @@ static int forward_counts_impl(const kge_model_desc *m, const float *d_ent, cons
         int32_t *totals = g_c.tile_hist, *cursor = g_c.tile_hist + (NB + 2);
         int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
         SegPlan plan;
-        plan.chunks = g_c.chunks; plan.n_chunks = g_c.n_chunks; plan.row_state = g_c.row_state; plan.E = (int)m->ent_total; plan.cap = cap;
-        hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals, g_c.n_chunks);
-        launch_bkt_scatter(n_tiles, (int)M, rpb, totals, cursor, pairs, stream);
-        hipLaunchKernelGGL(bkt_sort_kernel<true>, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
+        plan.row_span = g_c.row_span; plan.pieces = g_c.pieces; plan.n_pieces = g_c.n_pieces; plan.cap = cap;
+        hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb2, totals, g_c.n_pieces);
+        launch_bkt_scatter(n_tiles, (int)M, rpb2, totals, cursor, pairs, stream);
+        hipLaunchKernelGGL(bkt_sort_kernel<true>, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb2, stream, pairs, g_c.bucket_start, rpb2, rows2,
                            g_c.dst_sorted, g_c.ids_sorted, totals, cursor, plan);
         const long long all_rows = m->ent_total + m->rel_total;
         SegApplyArgs sa = {};
-        sa.rec = g_c.rec; sa.rec2 = rec2; sa.keys = g_c.dst_sorted; sa.ids = g_c.ids_sorted; sa.chunks = g_c.chunks; sa.n_chunks = g_c.n_chunks;
-        sa.n8 = 3 * (long long)n_pos; sa.RD = (int)rd; sa.S = d_counts; sa.fold_R = (int)m->rel_total;
+        sa.rec = g_c.rec; sa.rec2_off = (unsigned)((size_t)3 * (size_t)n_pos * rd * 4); sa.ids = g_c.ids_sorted; sa.row_span = g_c.row_span;
+        sa.pieces = g_c.pieces; sa.n_pieces = g_c.n_pieces;
+        sa.n8 = (int)(3 * n_pos); sa.m_last = (int)M - 1; sa.n_rows_v = rows; sa.RD = (int)rd; sa.cap = cap; sa.S = d_counts; sa.fold_R = (int)m->rel_total; sa.diag = engine().counts_fused_diag;
         ApplyArgs &a = sa.ap;
         a.p = fo->p[0]; a.p2 = fo->p[1]; a.resid = d_resid_ent; a.resid2 = d_resid_rel;
         if (fo->adam) { a.m = fo->m[0]; a.m2 = fo->m[1]; a.v = fo->v[0]; a.v2 = fo->v[1]; }
         a.S = d_counts; a.rows = all_rows; a.row_lo = 0; a.E = m->ent_total; a.D = D;
         a.unit = 1.0f / (float)denom; a.lr = fo->lr; a.b1 = fo->b1; a.b2 = fo->b2; a.eps = fo->eps; a.adam = fo->adam;
-        a.row_state = g_c.row_state;
+        a.row_span = g_c.row_span; a.span_cap = cap;
         {
             Engine &e = engine();     // (as kge_transe_apply_counts_range: the two kernels together rewrite every row's 1/|row| entry)
             const bool keeps = e.inv_carry && e.inv_valid && e.inv_norm && e.inv_for_ent == fo->p[0] && e.inv_for_rel == fo->p[1] && e.inv_cap >= all_rows;
@@ -1477,7 +1471,7 @@ static int forward_counts_impl(const kge_model_desc *m, const float *d_ent, cons
         }
 #define KGE_SEGAPPLY(LL, CC)                                                                                          \
     {                                                                                                                 \
-        const long long nb = (max_chunks + (256 / LL) - 1) / (256 / LL);                                              \
+        const long long nb = ((long long)rows + max_pieces + (256 / LL) - 1) / (256 / LL);                            \
         hipLaunchKernelGGL((segapply_kernel<LL, CC>), dim3((unsigned)nb), dim3(256), 0, stream, sa);                   \
         long long nb2 = (all_rows + (256 / LL) - 1) / (256 / LL);                                                     \
         if (nb2 > 8192) nb2 = 8192;                                                                                   \
