@@ -111,8 +111,13 @@ const char *kge_version(void);
  *   "counts_force_sort": 1 = order the sign-count records with rocPRIM's radix sort instead of the
  *                        hand-written two-level counting sort (default 0)
  *   "counts_fused":      1 (default) = kge_transe_train_step_counts sums the records of a row and applies the optimizer to it in one
- *                        kernel (rows of up to 3 x team-width records; longer rows and relation rows go through the count image);
+ *                        kernel (rows whose int8 and 2-bit record lists hold up to 64 records each; longer rows and relation rows go through the count image);
  *                        0 = the two-kernel form (segmented sum into the image, then kge_transe_apply_counts_tables).  Same bits.
+ *   "ride_shares":       where an armed sampler (kge_sampling_attach) rides: percent of its workgroups for the bucket histogram /
+ *                        bucket scatter / bucket sort / the launch that ends the step, one byte each (default 100 << 8: all of it in
+ *                        the scatter launch; parts that no launch took are launched by kge_sampling_flush)
+ *   "counts_fused_diag": measurement hook of the fused kernel (1: no record loops, 2: no row update, 4: no record loads, 8: no sums);
+ *                        any value but 0 gives WRONG results
  *   "counts_fused_cap":  test hook: rows of more than this many records take the image path (0 = the kernel's capacity)
  *   "inv_table_max_bytes": the TransE emit kernel reads 1/|row| from a per-row table rebuilt every step while
  *                        the two tables are at most this many bytes (default 256 MiB); larger tables (or 0)

@@ -86,6 +86,10 @@ struct Engine {
     int persist_trace = 0;      // measurement hook: the persistent launch stamps its phase boundaries (kge_persistent_trace)
     int persist_threads = 512;  // threads per workgroup of the persistent launch (512, or 1024: spills at its 128-register cap, measured slower)
     int counts_force_sort = 0;  // test hook: take the sort+segsum reduction even for small tables
+    // percent of an armed sampler's workgroups riding in bkt_hist / bkt_scatter / bkt_sort / the launch that ends the step (byte 0..3).
+    // Default: all of it in the scatter launch.  Spread 20/35/20/25 over the four it was SLOWER (their sum 68 -> 76 us per bench step):
+    // a part of the sampler takes a full latency chain (~8 us) however small it is, and it did not hide behind the host kernels.
+    int ride_shares = 100 << 8;
     int counts_fused = 1;       // kge_transe_train_step_counts: 1 = segmented sum and optimizer in one kernel (segapply_kernel); 0 = segsum + apply kernels
     int counts_fused_diag = 0;  // measurement hook, see SegApplyArgs::diag
     int counts_fused_cap = 0;   // test hook: rows of more than this many records go through the count image (0 = the kernel's capacity, 3 x team width)
@@ -96,7 +100,7 @@ Engine &engine();
 inline void tables_written() { engine().inv_valid = 0; }
 // sampler.hip: the next batch's sampler riding in another kernel's launch (kge_sampling_attach)
 struct SamplerArgs;
-bool take_attached_sampler(SamplerArgs &a, unsigned &blocks);   // true: `a` / `blocks` describe it and it is no longer armed
+bool take_attached_sampler(SamplerArgs &a, unsigned &blocks, float share = 1.0f);   // true: `a` / `blocks` describe the part taken (sampler.hip)
 int flush_attached_sampler(hipStream_t stream);                 // launches an armed sampler on its own
 int attach_sampler(int32_t *d_h, int32_t *d_t, int32_t *d_r, int64_t B, int64_t neg, int64_t negrel, int64_t thread_lo,
                    int64_t thread_hi, int64_t out_stride, int64_t *n_local_out, hipStream_t stream);

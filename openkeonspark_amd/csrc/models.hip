@@ -661,7 +661,7 @@ template <int MODEL, int L, int C>
 __global__ __launch_bounds__(256) void fwdbwd_ride_kernel(FbArgs a, SamplerArgs ride, int n_ride) {
     if ((int)blockIdx.x >= a.loss_blocks) {
         __shared__ float bern_lds[kBernLds];
-        sample_block(ride, (long long)blockIdx.x - a.loss_blocks, n_ride, bern_lds);
+        sample_block_ride(ride, (long long)blockIdx.x - a.loss_blocks, bern_lds);
         return;
     }
     fwdbwd_body<MODEL, L, C, false>(a);
@@ -670,7 +670,7 @@ template <int MODEL, int L, int C>
 __global__ __launch_bounds__(256, 4) void fwdbwd_ride_kernel_occ4(FbArgs a, SamplerArgs ride, int n_ride) {   // (see fwdbwd_kernel_occ4)
     if ((int)blockIdx.x >= a.loss_blocks) {
         __shared__ float bern_lds[kBernLds];
-        sample_block(ride, (long long)blockIdx.x - a.loss_blocks, n_ride, bern_lds);
+        sample_block_ride(ride, (long long)blockIdx.x - a.loss_blocks, bern_lds);
         return;
     }
     fwdbwd_body<MODEL, L, C, false>(a);

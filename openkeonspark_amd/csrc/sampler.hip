@@ -19,6 +19,12 @@ __global__ __launch_bounds__(256) void sample_kernel(SamplerArgs a) {
     sample_block(a, blockIdx.x, gridDim.x, bern_lds);
 }
 
+// what is left of an armed sampler after parts of it rode in other launches
+__global__ __launch_bounds__(256) void sample_kernel_part(SamplerArgs a) {
+    __shared__ float bern_lds[kBernLds];
+    sample_block_ride(a, blockIdx.x, bern_lds);
+}
+
 // The same advance in place, for a launch whose own slice is empty (a data-parallel rank without positions).
 __global__ void advance_streams_kernel(uint64_t *streams, long long W, long long B, long long per_thread,
                                        unsigned long long draws) {
@@ -86,12 +92,21 @@ static int build_sampler(int32_t *d_h, int32_t *d_t, int32_t *d_r, int64_t B, in
 // progress takes it along as extra workgroups (transe_counts.hip), kge_sampling_flush launches it on its own otherwise.
 static bool g_att_armed = false, g_att_wide = false;
 static SamplerArgs g_att;
-static unsigned g_att_blocks = 0;
+static unsigned g_att_blocks = 0, g_att_next = 0;     // workgroups of the armed sampler; the first one not handed out yet
 
-bool take_attached_sampler(SamplerArgs &a, unsigned &blocks) {
+// `share` of the armed sampler's workgroups (1 = all that is left) for the caller's launch: a.ride_first / a.ride_total say which,
+// `blocks` how many extra workgroups the launch needs (sample_block_ride).  The small kernels of a step each leave most of the
+// chip idle; the sampler -- a latency-bound pointer chase independent of the step -- is spread over several of them.
+bool take_attached_sampler(SamplerArgs &a, unsigned &blocks, float share) {
     if (!g_att_armed || g_att_wide || g_att_blocks == 0) return false;
-    a = g_att; blocks = g_att_blocks;
-    g_att_armed = false;
+    const unsigned left = g_att_blocks - g_att_next;
+    unsigned want = share >= 1.0f ? left : (unsigned)(share * (float)g_att_blocks + 0.5f);
+    if (want > left) want = left;
+    if (want == 0) return false;
+    a = g_att; a.ride_first = g_att_next; a.ride_total = g_att_blocks;
+    blocks = want;
+    g_att_next += want;
+    if (g_att_next >= g_att_blocks) g_att_armed = false;
     return true;
 }
 
@@ -99,7 +114,12 @@ int flush_attached_sampler(hipStream_t stream) {
     if (!g_att_armed) return KGE_OK;
     g_att_armed = false;
     if (g_att_wide) hipLaunchKernelGGL(sample_kernel_wide, dim3(g_att_blocks), dim3(256), 0, stream, g_att);
-    else hipLaunchKernelGGL(sample_kernel, dim3(g_att_blocks), dim3(256), 0, stream, g_att);
+    else if (g_att_next == 0) hipLaunchKernelGGL(sample_kernel, dim3(g_att_blocks), dim3(256), 0, stream, g_att);
+    else {
+        SamplerArgs a = g_att;
+        a.ride_first = g_att_next; a.ride_total = g_att_blocks;
+        hipLaunchKernelGGL(sample_kernel_part, dim3(g_att_blocks - g_att_next), dim3(256), 0, stream, a);
+    }
     return hip_check(hipGetLastError(), "sampler launch");
 }
 
@@ -116,7 +136,7 @@ int attach_sampler(int32_t *d_h, int32_t *d_t, int32_t *d_r, int64_t B, int64_t 
         e.dev.streams_sync = 2;
         return hip_check(hipGetLastError(), "sampler launch");
     }
-    g_att = a; g_att_blocks = blocks; g_att_wide = wide; g_att_armed = true;
+    g_att = a; g_att_blocks = blocks; g_att_next = 0; g_att_wide = wide; g_att_armed = true;
     std::swap(e.dev.streams, e.dev.streams_next);     // the armed launch reads the current half and writes the other one
     e.dev.streams_sync = 2;
     return KGE_OK;

@@ -35,6 +35,9 @@ struct SamplerArgs {
     int ent_total, rel_total;
     int neg, negrel, bern;
     int kshift;            // log2 of the lane slots per positive
+    // a PART of the sampler's grid riding in another kernel's launch (take_attached_sampler): the rider's extra workgroup i runs
+    // workgroup ride_first + i of ride_total
+    unsigned ride_first, ride_total;
 };
 
 __device__ __forceinline__ uint64_t lcg_step(uint64_t s) { return s * kLcgMul + kLcgAdd; }
@@ -251,5 +254,10 @@ __device__ __forceinline__ void sample_block(const SamplerArgs &a, long long blo
     }
 }
 
+
+// workgroup `i` of the part of an armed sampler that rides in this launch
+__device__ __forceinline__ void sample_block_ride(const SamplerArgs &a, long long i, float *bern_lds) {
+    sample_block(a, (long long)a.ride_first + i, (long long)a.ride_total, bern_lds);
+}
 
 }  // namespace kge

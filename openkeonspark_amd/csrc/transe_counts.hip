@@ -348,9 +348,14 @@ __device__ __forceinline__ int bucket_of(int d, int rpb) { return d < 0 ? NB : d
 
 // bucket_total[b] += number of records of this tile that fall into bucket b
 __global__ __launch_bounds__(256) void bkt_hist_kernel(const int32_t *__restrict__ dst, int M, int rpb, int32_t *__restrict__ bucket_total,
-                                                       int32_t *__restrict__ plan_counter = nullptr) {
+                                                       int32_t *__restrict__ plan_counter, SamplerArgs ride, int n_tiles) {
+    if ((int)blockIdx.x >= n_tiles) {      // a part of the next batch's sampler riding along (see bkt_scatter_kernel)
+        __shared__ float bern_lds[kBernLds];
+        sample_block_ride(ride, (long long)blockIdx.x - n_tiles, bern_lds);
+        return;
+    }
     __shared__ int hist[NB + 1];
-    if (plan_counter && blockIdx.x == 0 && threadIdx.x == 0) plan_counter[0] = 0;   // fused step: the chunk counter bkt_sort_kernel<true> adds to
+    if (plan_counter && blockIdx.x == 0 && threadIdx.x == 0) plan_counter[0] = 0;   // fused step: the piece counter bkt_sort_kernel<true> adds to
     for (int i = threadIdx.x; i <= NB; i += 256) hist[i] = 0;
     __syncthreads();
     const int base = blockIdx.x * BTILE;
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(256) void bkt_scatter_kernel(const int32_t *__restr
                                                           int2 *__restrict__ pairs, SamplerArgs ride, int n_tiles, int n_ride) {
     if ((int)blockIdx.x >= n_tiles) {
         __shared__ float bern_lds[kBernLds];
-        sample_block(ride, (long long)blockIdx.x - n_tiles, n_ride, bern_lds);
+        sample_block_ride(ride, (long long)blockIdx.x - n_tiles, bern_lds);
         return;
     }
     __shared__ int hist[NB + 1];
@@ -438,12 +443,24 @@ __global__ __launch_bounds__(256) void bkt_scatter_kernel(const int32_t *__restr
 }
 
 
-// the bucket scatter, with an armed sampler (if any) riding along
+// The three bucketing launches (and the launch that ends the step) can each take a PART of an armed sampler along: engine option
+// "ride_shares", percent of the sampler's workgroups for hist / scatter / sort / closing launch.  Default: all of it in the
+// scatter launch (measured: spreading it made the step slower, see engine.hpp).
+static unsigned take_ride(SamplerArgs &ride, int which) {
+    unsigned n_ride = 0;
+    const int pct = (engine().ride_shares >> (8 * which)) & 0xFF;
+    // this translation unit's copy of the jump table first: an armed sampler is only taken along once it can run here
+    if (pct == 0 || upload_jump_table() != KGE_OK || !take_attached_sampler(ride, n_ride, pct >= 100 ? 1.0f : 0.01f * (float)pct)) n_ride = 0;
+    return n_ride;
+}
+static void launch_bkt_hist(int n_tiles, int M, int rpb, int32_t *totals, int32_t *plan_counter, hipStream_t stream) {
+    SamplerArgs ride = {};
+    const unsigned n_ride = take_ride(ride, 0);
+    hipLaunchKernelGGL(bkt_hist_kernel, dim3((unsigned)n_tiles + n_ride), dim3(256), 0, stream, g_c.dst, M, rpb, totals, plan_counter, ride, n_tiles);
+}
 static void launch_bkt_scatter(int n_tiles, int M, int rpb, int32_t *totals, int32_t *cursor, int2 *pairs, hipStream_t stream) {
     SamplerArgs ride = {};
-    unsigned n_ride = 0;
-    // this translation unit's copy of the jump table first: an armed sampler is only taken along once it can run here
-    if (upload_jump_table() == KGE_OK && !take_attached_sampler(ride, n_ride)) n_ride = 0;
+    const unsigned n_ride = take_ride(ride, 1);
     hipLaunchKernelGGL(bkt_scatter_kernel, dim3((unsigned)n_tiles + n_ride), dim3(256), 0, stream, g_c.dst, M, rpb, totals, g_c.bucket_start,
                        cursor, pairs, ride, n_tiles, (int)n_ride);
 }
@@ -469,8 +486,13 @@ template <bool PLAN>
 __global__ __launch_bounds__(256) void bkt_sort_kernel(const int2 *__restrict__ pairs, const int32_t *__restrict__ bucket_start,
                                                        int rpb, int rows, int32_t *__restrict__ out_keys,
                                                        int32_t *__restrict__ out_ids, int32_t *__restrict__ bucket_total,
-                                                       int32_t *__restrict__ cursor, SegPlan plan) {
+                                                       int32_t *__restrict__ cursor, SegPlan plan, SamplerArgs ride) {
     extern __shared__ int lds_h[];   // [rpb] histogram, then running offsets
+    if ((int)blockIdx.x >= NB) {           // a part of the next batch's sampler riding along (see bkt_scatter_kernel)
+        __shared__ float bern_lds[kBernLds];
+        sample_block_ride(ride, (long long)blockIdx.x - NB, bern_lds);
+        return;
+    }
     const int b = blockIdx.x;
     const int row0 = b * rpb;
     if (threadIdx.x == 0) {   // totals and cursors back to zero for the next step (block 0 also the trash bucket's)
@@ -554,6 +576,14 @@ __global__ __launch_bounds__(256) void bkt_sort_kernel(const int2 *__restrict__ 
     }
 }
 
+
+template <bool PLAN>
+static void launch_bkt_sort(int2 *pairs, int rpb, int rows, int32_t *totals, int32_t *cursor, const SegPlan &plan, hipStream_t stream) {
+    SamplerArgs ride = {};
+    const unsigned n_ride = take_ride(ride, 2);
+    hipLaunchKernelGGL(bkt_sort_kernel<PLAN>, dim3(NB + n_ride), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
+                       g_c.dst_sorted, g_c.ids_sorted, totals, cursor, plan, ride);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Sparse form (tables too large for a dense [rows, D] count image, and the multi-GPU record exchange):
@@ -897,10 +927,9 @@ int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t 
         }
         int32_t *totals = g_c.tile_hist, *cursor = g_c.tile_hist + (NB + 2);
         int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
-        hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals);
+        launch_bkt_hist(n_tiles, (int)M, rpb, totals, nullptr, stream);
         launch_bkt_scatter(n_tiles, (int)M, rpb, totals, cursor, pairs, stream);
-        hipLaunchKernelGGL(bkt_sort_kernel<false>, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
-                           g_c.dst_sorted, g_c.ids_sorted, totals, cursor, SegPlan());
+        launch_bkt_sort<false>(pairs, rpb, rows, totals, cursor, SegPlan(), stream);
         n_valid_p = g_c.bucket_start + NB;
     } else {
         int blocks = (int)((M + 255) / 256);
@@ -964,10 +993,9 @@ int pair_records_reduce(int model, int64_t M, int64_t n_int8, int D, int rd, int
         }
         int32_t *totals = g_c.tile_hist, *cursor = g_c.tile_hist + (NB + 2);
         int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
-        hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals);
+        launch_bkt_hist(n_tiles, (int)M, rpb, totals, nullptr, stream);
         launch_bkt_scatter(n_tiles, (int)M, rpb, totals, cursor, pairs, stream);
-        hipLaunchKernelGGL(bkt_sort_kernel<false>, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
-                           g_c.dst_sorted, g_c.ids_sorted, totals, cursor, SegPlan());
+        launch_bkt_sort<false>(pairs, rpb, rows, totals, cursor, SegPlan(), stream);
         n_valid_p = g_c.bucket_start + NB;   // start of the trash bucket == number of live records
     } else {
         // larger key spaces (e.g. FB15k: 14 951 entities x 1 345 relations): rocPRIM's radix sort on the same keys
@@ -1129,14 +1157,22 @@ __device__ __forceinline__ bool apply_row_update(const Team<L, C> &tm, const App
     return true;
 }
 
+// n_own > 0: workgroups from n_own on run a part of the next batch's sampler (the launch that ends a single-process step takes
+// what the bucketing launches left of it, see launch_bkt_hist)
 template <int L, int C, bool SPARSE>
-__global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a) {
+__global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a, SamplerArgs ride = SamplerArgs(), int n_own = 0) {
     constexpr int TEAMS = 256 / L;
+    if (n_own > 0 && (int)blockIdx.x >= n_own) {
+        __shared__ float bern_lds[kBernLds];
+        sample_block_ride(ride, (long long)blockIdx.x - n_own, bern_lds);
+        return;
+    }
+    const long long n_blocks = n_own > 0 ? n_own : gridDim.x;
     Team<L, C> tm;
     tm.lane = threadIdx.x % L;
     tm.D = a.D;
     const long long n_rows = SPARSE ? (long long)a.n_rows[0] : a.rows;
-    for (long long i = a.row_lo + (long long)blockIdx.x * TEAMS + threadIdx.x / L; i < n_rows; i += (long long)gridDim.x * TEAMS) {
+    for (long long i = a.row_lo + (long long)blockIdx.x * TEAMS + threadIdx.x / L; i < n_rows; i += n_blocks * TEAMS) {
         long long row = SPARSE ? (long long)a.row_list[i] : i;
         // behind the fused segmented-sum-and-apply kernel: the entity rows it has already updated from registers are skipped
         if (!SPARSE && a.row_span && row < a.E && a.row_span[2 * row].y <= a.span_cap && a.row_span[2 * row + 1].y <= a.span_cap) continue;
@@ -1448,10 +1484,9 @@ static int forward_counts_impl(const kge_model_desc *m, const float *d_ent, cons
         int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
         SegPlan plan;
         plan.row_span = g_c.row_span; plan.pieces = g_c.pieces; plan.n_pieces = g_c.n_pieces; plan.cap = cap;
-        hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb2, totals, g_c.n_pieces);
+        launch_bkt_hist(n_tiles, (int)M, rpb2, totals, g_c.n_pieces, stream);
         launch_bkt_scatter(n_tiles, (int)M, rpb2, totals, cursor, pairs, stream);
-        hipLaunchKernelGGL(bkt_sort_kernel<true>, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb2, stream, pairs, g_c.bucket_start, rpb2, rows2,
-                           g_c.dst_sorted, g_c.ids_sorted, totals, cursor, plan);
+        launch_bkt_sort<true>(pairs, rpb2, rows2, totals, cursor, plan, stream);
         const long long all_rows = m->ent_total + m->rel_total;
         SegApplyArgs sa = {};
         sa.rec = g_c.rec; sa.rec2_off = (unsigned)((size_t)3 * (size_t)n_pos * rd * 4); sa.ids = g_c.ids_sorted; sa.row_span = g_c.row_span;
@@ -1475,7 +1510,9 @@ static int forward_counts_impl(const kge_model_desc *m, const float *d_ent, cons
         hipLaunchKernelGGL((segapply_kernel<LL, CC>), dim3((unsigned)nb), dim3(256), 0, stream, sa);                   \
         long long nb2 = (all_rows + (256 / LL) - 1) / (256 / LL);                                                     \
         if (nb2 > 8192) nb2 = 8192;                                                                                   \
-        hipLaunchKernelGGL((apply_counts_kernel<LL, CC, false>), dim3((unsigned)nb2), dim3(256), 0, stream, a);        \
+        SamplerArgs ride = {};                                                                                        \
+        const unsigned n_ride = take_ride(ride, 3);                                                                   \
+        hipLaunchKernelGGL((apply_counts_kernel<LL, CC, false>), dim3((unsigned)nb2 + n_ride), dim3(256), 0, stream, a, ride, (int)nb2); \
     }
         if (D <= 64) KGE_SEGAPPLY(16, 4) else if (D <= 128) KGE_SEGAPPLY(32, 4) else if (D <= 256) KGE_SEGAPPLY(64, 4)
         else if (D <= 512) KGE_SEGAPPLY(64, 8) else KGE_SEGAPPLY(64, 16)
@@ -1493,10 +1530,9 @@ static int forward_counts_impl(const kge_model_desc *m, const float *d_ent, cons
         }
         int32_t *totals = g_c.tile_hist, *cursor = g_c.tile_hist + (NB + 2);
         int2 *pairs = reinterpret_cast<int2 *>(g_c.pairs);
-        hipLaunchKernelGGL(bkt_hist_kernel, dim3(n_tiles), dim3(256), 0, stream, g_c.dst, (int)M, rpb, totals);
+        launch_bkt_hist(n_tiles, (int)M, rpb, totals, nullptr, stream);
         launch_bkt_scatter(n_tiles, (int)M, rpb, totals, cursor, pairs, stream);
-        hipLaunchKernelGGL(bkt_sort_kernel<false>, dim3(NB), dim3(256), sizeof(int) * (size_t)rpb, stream, pairs, g_c.bucket_start, rpb, rows,
-                           g_c.dst_sorted, g_c.ids_sorted, totals, cursor, SegPlan());
+        launch_bkt_sort<false>(pairs, rpb, rows, totals, cursor, SegPlan(), stream);
         const int32_t *n_valid_p = g_c.bucket_start + NB;   // start of the trash bucket == number of live records
 #define KGE_SEG2(LL, CC)                                                                                              \
     {                                                                                                                 \
@@ -1801,7 +1837,9 @@ int kge_transe_apply_counts_range(const kge_model_desc *m, float *const d_p[2], 
     {                                                                                                       \
         long long nb = (rows + (256 / LL) - 1) / (256 / LL);                                                \
         if (nb > 8192) nb = 8192;                                                                           \
-        hipLaunchKernelGGL((apply_counts_kernel<LL, CC, false>), dim3((unsigned)nb), dim3(256), 0, stream, a); \
+        SamplerArgs ride = {};                                                                              \
+        const unsigned n_ride = take_ride(ride, 3);                                                         \
+        hipLaunchKernelGGL((apply_counts_kernel<LL, CC, false>), dim3((unsigned)nb + n_ride), dim3(256), 0, stream, a, ride, (int)nb); \
     }
     KGE_SHAPE_DISPATCH(D, KGE_APPLY2)
 #undef KGE_APPLY2

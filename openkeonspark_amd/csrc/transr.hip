@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void rel_scatter_kernel(const int32_t *__restr
     // hundred workgroups and leaves the chip idle, the sampler is independent of everything in the step
     if ((int)blockIdx.x >= n_own) {
         __shared__ float bern_lds[kBernLds];
-        sample_block(ride, (long long)blockIdx.x - n_own, n_ride, bern_lds);
+        sample_block_ride(ride, (long long)blockIdx.x - n_own, bern_lds);
         return;
     }
     const int bins = (R + 1) * kRelSub;
