@@ -116,7 +116,7 @@ const char *kge_version(void);
  *   "ride_shares":       where an armed sampler (kge_sampling_attach) rides: percent of its workgroups for the bucket histogram /
  *                        bucket scatter / bucket sort / the launch that ends the step, one byte each (default 100 << 8: all of it in
  *                        the scatter launch; parts that no launch took are launched by kge_sampling_flush)
- *   "counts_fused_diag": measurement hook of the fused kernel (1: no record loops, 2: no row update, 4: no record loads, 8: no sums);
+ *   "counts_fused_diag": measurement hook of the fused kernel (1: no record loops, 2: no row update);
  *                        any value but 0 gives WRONG results
  *   "counts_fused_cap":  test hook: rows of more than this many records take the image path (0 = the kernel's capacity)
  *   "inv_table_max_bytes": the TransE emit kernel reads 1/|row| from a per-row table rebuilt every step while
