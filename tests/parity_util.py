@@ -281,7 +281,8 @@ def check_transe_adam_step(tot, step, p0, m0, v0, p1, m1, v1, g_o, p1_oracle, bh
         tot["rows_in_kink_set"] += len(in_set[k])
         tot["rows_fully_checked"] += diff.shape[0] - len(bad)
         clean = np.ones(diff.shape[0], bool); clean[bad] = False
-        tot["grad"] = max(tot["grad"], float(diff[clean].max() / scale))
+        # (net of the fp32 storage quantum of the first moment the gradient is read back from: the same allowance as in `bad`)
+        tot["grad"] = max(tot["grad"], float(np.maximum(diff[clean] - quantum, 0.0).max() / scale))
         g_chk = g_o[k].astype(np.float64).copy()
         g_chk[bad] = g_eng[bad]
         atol = np.zeros_like(g_chk); atol[bad] = quantum
