@@ -173,8 +173,41 @@ def test_forward_backward_matches_oracle(model, E, R, D, n, nr, foreign, grad_pa
     loss_g = float(con._loss.item())
     g_g = con.get_gradients()
     assert abs(loss_g - loss_o) <= RTOL * abs(loss_o), (loss_g, loss_o)
+    check_gradients_with_kinks(model, params, bh, bt, br, B, n + nr, D, nr, orc, g_g, g_o)
+
+
+def check_gradients_with_kinks(model, params, bh, bt, br, B, N, D, nr, orc, g_g, g_o):
+    """Every row within RTOL of the oracle's -- except rows reached by a KINK: an element of e = h^ + r^ - t^ within 1e-7 of zero
+    (fp64) gets sign +1 from one correct fp32 evaluation and -1 or 0 from another (batch_without_ties keeps the hinges away from
+    their switch points, the kinks it cannot avoid: seen with |e| = 1.5e-9).  Such rows are not waved through: for TransE the
+    difference must lie inside what the kink elements of the row's own slots allow (parity_util.transe_row_radius); for the
+    projecting models, whose rows see a kink through the projection, it is bounded by the flips' total weight."""
+    from parity_util import transe_switch_points, transe_row_radius
+    from torch_ref import near_kink_rows
+    bad = {k: np.nonzero((np.abs(g_g[k] - g_o[k]) > RTOL * (np.abs(g_o[k]).max() + 1e-30)).reshape(g_o[k].shape[0], -1).any(1))[0] for k in g_o}
+    if not any(len(v) for v in bad.values()):
+        return
+    kink, n_el = near_kink_rows(model, params, bh, bt, br, B, N, D, D, tol=1e-7, negative_rel=nr)
+    assert n_el > 0, ("gradient rows outside 1e-5 and no element of e near zero", {k: v[:5].tolist() for k, v in bad.items()})
+    parity_report("forward_backward kink rows", model=model, dim=D, kink_elements=n_el, rows_outside={k: len(v) for k, v in bad.items()})
+    if model == "transe" and nr == 0:
+        hm = orc.hinge_margins(bh, bt, br, B, N)
+        kinks, ties, w_max = transe_switch_points(params, bh, bt, br, B, N, hm, 1e-7, 0.0)
+        for k in g_o:
+            scale = np.abs(g_o[k]).max()
+            for row in bad[k].tolist():
+                rad = transe_row_radius(params, bh, bt, br, B, N, k, row, kinks, ties, w_max)
+                assert (np.abs(g_g[k][row].astype(np.float64) - g_o[k][row]) <= rad + RTOL * scale).all(), (k, row)
+        return
+    unit = 1.0 / (B * N)
     for k in g_o:
-        assert relerr(g_g[k], g_o[k]) < RTOL, (k, relerr(g_g[k], g_o[k]))
+        assert set(bad[k].tolist()) <= kink[k], (k, sorted(set(bad[k].tolist()) - kink[k])[:5])
+        assert len(bad[k]) <= 8 * n_el
+        # one flipped sign moves dL/d(normalised vector) by at most 2 (1 + N) / (B N) per element; the backward through normalise and
+        # projection does not amplify it beyond a few 1 / |row|
+        min_norm = np.sqrt((np.asarray(params[k], dtype=np.float64) ** 2).sum(1)).min()
+        if len(bad[k]):
+            assert np.abs(g_g[k][bad[k]] - g_o[k][bad[k]]).max() <= n_el * 8 * (1 + N) * unit / max(min_norm, 1e-6), k
 
 
 def adam_step_explained(con, orc, model, bh, bt, br, B, n, alpha, dims, step_index, tag):
