@@ -373,6 +373,10 @@ int kge_transe_apply_rows_sgd(const kge_model_desc *m, float *d_ent, float *d_re
  * AdamOptimizer moves every row of the table every step, distribute_training.py:96 -- kge_transe_apply_counts / kge_adam_dense
  * are the parity path).  For tables whose dense sweep (32 bytes per element per step) would dominate the step.  lr_t =
  * lr sqrt(1 - b2^t) / (1 - b1^t) with the global step t, computed by the caller. */
+/* The NEXT kge_transe_apply_rows_adam_lazy call processes listed row i only where d_row_live[i] != 0 (one call, then back to "every
+ * listed row").  For the table-sharded data-parallel step: the replicated relation rows are listed in full with their all-reduced
+ * counts, and a relation for which NO rank had a record must keep its row and moments (the lazy rule). */
+int kge_transe_lazy_row_live(const int32_t *d_row_live);
 int kge_transe_apply_rows_adam_lazy(const kge_model_desc *m, float *d_ent, float *d_rel, float *d_m_ent, float *d_m_rel, float *d_v_ent,
                                     float *d_v_rel, const int32_t *d_rows, const int32_t *d_row_counts, const int32_t *d_n_rows,
                                     INT max_rows, INT denom, float lr_t, float beta1, float beta2, float eps, void *stream);

@@ -360,8 +360,6 @@ class Config(object):
         self._n_local = self.lib.kge_slice_positions(self.batch_size, lo, hi, ctypes.byref(first))
         self._first_pos = first.value
         if self._dp and self.trainModel is not None and getattr(self, "_dist_ready", 0) != self.world_size:
-            if getattr(self, "_lazy_adam", False):
-                raise KgeError("LazyAdam is single-process (the sharded path keeps no moment shards)")
             if getattr(self, "sparse_inplace", False):
                 raise KgeError("row-wise SGD in place (sparse_rows with TransH / TransD) is single-process")
             if self.sparse_rows:
@@ -473,6 +471,13 @@ class Config(object):
         self.trainModel.parameter_lists["ent_embeddings"] = shard
         self.trainModel.ent_embeddings = shard
         del full
+        if self._lazy_adam:     # the moments of the entity rows are sharded with them (owner computes); the relation table's stay replicated
+            for slots in (self._adam_m, self._adam_v):
+                old = slots[0]
+                slots[0] = torch.zeros((chunk, D), dtype=torch.float32, device=shard.device)
+                if hi > lo:
+                    slots[0][:hi - lo].copy_(old[lo:hi])
+                del old
         torch.cuda.empty_cache()
         self._shard = dict(chunk=chunk, lo=lo, hi=hi)
         self._refresh_pointers()
@@ -1053,6 +1058,16 @@ class Config(object):
                                              b["dst"].data_ptr(), None, None, self._loss.data_ptr(), st), L)
         # 4. relation rows: dense int32 image, all-reduced (the relation table is replicated)
         b["rel_counts"].zero_()
+        if self._lazy_adam:
+            # which relations have a record on THIS rank -- the relation-slot destinations of its active groups (before the reduce below
+            # rewrites the destination keys in place); summed over the ranks with the counts.  Entry R collects the inactive groups.
+            if "rel_live" not in b:
+                b["rel_live"] = torch.zeros(self.relTotal + 1, dtype=torch.int32, device=self.device)
+            b["rel_live"].zero_()
+            if n_pos > 0:
+                d = b["dst"][2 * n_pos:3 * n_pos]
+                idx = torch.where(d >= 0, d - int(desc2.ent_total), torch.full_like(d, self.relTotal))
+                b["rel_live"].index_fill_(0, idx.long(), 1)
         if D % 4 == 0 and self.negative_rel == 0 and n_pos > 0:
             # the relation-side records are slot 2 of every group -- records [2 n_pos, 3 n_pos): ordered by relation, summed by
             # segments into <= R compact rows, scattered into the image (per-element atomics took 0.4 ms of a 3 ms step)
@@ -1068,7 +1083,10 @@ class Config(object):
         else:
             _lib.check(L.kge_shard_relation_counts(b["rec"].data_ptr(), b["dst"].data_ptr(), M, desc2.ent_total, self.relTotal, dw, D,
                                                    b["rel_counts"].data_ptr(), st), L)
-        par.allreduce_sum([b["rel_counts"], self._loss], pg)
+        if self._lazy_adam:
+            par.allreduce_sum([b["rel_counts"], self._loss, b["rel_live"]], pg)
+        else:
+            par.allreduce_sum([b["rel_counts"], self._loss], pg)
         # 5. entity records to their owners
         _lib.check(L.kge_shard_record_ids(b["dst"].data_ptr(), M, n_send, b["send_ids"].data_ptr(), b["ids2"].data_ptr(), st), L)
         _lib.check(L.kge_shard_count(b["ids2"].data_ptr(), M, chunk, W, b["counts"].data_ptr(), st), L)
@@ -1081,18 +1099,37 @@ class Config(object):
         b = self._shard_buffers(M, n_recv, n_recv2)
         par.all_to_all_rows(b["recv_rows2"], b["send_rows2"], recv2, send2, pg, max_rows=gmax2)
         par.all_to_all_rows(b["recv_rec"], b["send_rec"], recv2, send2, pg, max_rows=gmax2)
-        # 6. owner: sort by row, segmented sum, SGD on the touched rows of the shard
+        # 6. owner: sort by row, segmented sum, SGD (or lazy Adam: the shard's own moment rows) on the touched rows of the shard
         if n_recv2 > 0:
             b["recv_rows2"][:n_recv2].sub_(sh["lo"])
             desc3 = self._desc_with(ent_total=chunk, rel_total=0)
-            _lib.check(L.kge_transe_reduce_apply_records_sgd(
-                ctypes.byref(desc3), b["recv_rec"].data_ptr(), b["recv_rows2"].data_ptr(), n_recv2, self._tables[0].data_ptr(),
-                self._tables[1].data_ptr(), b["rows"].data_ptr(), b["row_counts"].data_ptr(), b["n_rows"].data_ptr(), denom,
-                float(self.alpha), st), L)
+            if self._lazy_adam:
+                _lib.check(L.kge_transe_reduce_records(ctypes.byref(desc3), b["recv_rec"].data_ptr(), b["recv_rows2"].data_ptr(), n_recv2,
+                                                       b["rows"].data_ptr(), b["row_counts"].data_ptr(), b["n_rows"].data_ptr(), st), L)
+                _lib.check(L.kge_transe_apply_rows_adam_lazy(
+                    ctypes.byref(desc3), self._tables[0].data_ptr(), self._tables[1].data_ptr(), self._adam_m[0].data_ptr(),
+                    self._adam_m[1].data_ptr(), self._adam_v[0].data_ptr(), self._adam_v[1].data_ptr(), b["rows"].data_ptr(),
+                    b["row_counts"].data_ptr(), b["n_rows"].data_ptr(), n_recv2, denom, float(self._adam_lr_t()), self.adam_beta1,
+                    self.adam_beta2, self.adam_epsilon, st), L)
+            else:
+                _lib.check(L.kge_transe_reduce_apply_records_sgd(
+                    ctypes.byref(desc3), b["recv_rec"].data_ptr(), b["recv_rows2"].data_ptr(), n_recv2, self._tables[0].data_ptr(),
+                    self._tables[1].data_ptr(), b["rows"].data_ptr(), b["row_counts"].data_ptr(), b["n_rows"].data_ptr(), denom,
+                    float(self.alpha), st), L)
         # 7. every rank applies the identical relation update from the all-reduced counts
-        _lib.check(L.kge_transe_apply_rows_sgd(ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(),
-                                               b["rel_rows"].data_ptr(), b["rel_counts"].data_ptr(), b["n_rel"].data_ptr(),
-                                               self.relTotal, denom, float(self.alpha), st), L)
+        if self._lazy_adam:
+            # (only the relations SOME rank had a record for: a record-less row keeps its value and moments under the lazy rule)
+            _lib.check(L.kge_transe_lazy_row_live(b["rel_live"].data_ptr()), L)
+            _lib.check(L.kge_transe_apply_rows_adam_lazy(
+                ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(), self._adam_m[0].data_ptr(),
+                self._adam_m[1].data_ptr(), self._adam_v[0].data_ptr(), self._adam_v[1].data_ptr(), b["rel_rows"].data_ptr(),
+                b["rel_counts"].data_ptr(), b["n_rel"].data_ptr(), self.relTotal, denom, float(self._adam_lr_t()), self.adam_beta1,
+                self.adam_beta2, self.adam_epsilon, st), L)
+            self._adam_advance()
+        else:
+            _lib.check(L.kge_transe_apply_rows_sgd(ctypes.byref(self._desc), self._tables[0].data_ptr(), self._tables[1].data_ptr(),
+                                                   b["rel_rows"].data_ptr(), b["rel_counts"].data_ptr(), b["n_rel"].data_ptr(),
+                                                   self.relTotal, denom, float(self.alpha), st), L)
         self.global_step += 1
 
     def sparse_row_gradients(self):

@@ -92,6 +92,7 @@ def _declare(L):
     L.kge_transe_apply_counts_tables.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, vp]
     L.kge_transe_train_step_counts.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, i32, i32,
                                                f32, f32, f32, f32, vp, vp]
+    L.kge_transe_lazy_row_live.argtypes = [vp]
     L.kge_transe_record_dwords.restype = i64
     L.kge_transe_record_dwords.argtypes = [ctypes.POINTER(ModelDesc)]
     L.kge_transe_emit_records.argtypes = [ctypes.POINTER(ModelDesc), vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]

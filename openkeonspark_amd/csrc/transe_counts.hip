@@ -1082,6 +1082,8 @@ struct ApplyArgs {
     float *p2, *m2, *v2, *resid2;
     long long E;
     long long row_lo;   // dense form on a row RANGE [row_lo, rows): S points at the image of row_lo (a rank's reduce-scattered chunk)
+    const int32_t *row_live;    // row-list form: listed row i is processed only where row_live[i] != 0 (null: every listed row).  The sharded
+                                // lazy-Adam step lists ALL relation rows with their all-reduced counts: a relation no rank had a record for must not move
     const int2 *row_span;       // fused step: (first position, records) per key 2 * row + kind; entity rows whose two lists hold at most
     int span_cap;               // span_cap records each were updated by segapply_kernel itself and are skipped here; null otherwise
     float *inv_out;     // dense full-table form: the emit kernel's 1/|row| table ([E + R], row-space index), refreshed for every row rewritten
@@ -1174,6 +1176,7 @@ __global__ __launch_bounds__(256) void apply_counts_kernel(ApplyArgs a, SamplerA
     const long long n_rows = SPARSE ? (long long)a.n_rows[0] : a.rows;
     for (long long i = a.row_lo + (long long)blockIdx.x * TEAMS + threadIdx.x / L; i < n_rows; i += n_blocks * TEAMS) {
         long long row = SPARSE ? (long long)a.row_list[i] : i;
+        if (SPARSE && a.row_live && a.row_live[i] == 0) continue;
         // behind the fused segmented-sum-and-apply kernel: the entity rows it has already updated from registers are skipped
         if (!SPARSE && a.row_span && row < a.E && a.row_span[2 * row].y <= a.span_cap && a.row_span[2 * row + 1].y <= a.span_cap) continue;
         float *table = a.p, *mt = a.m, *vt = a.v, *rt = a.resid;
@@ -1758,6 +1761,10 @@ int kge_transe_apply_rows_sgd(const kge_model_desc *m, float *d_ent, float *d_re
     return hip_check(hipGetLastError(), "apply rows launch");
 }
 
+static const int32_t *g_lazy_row_live = nullptr;     // kge_transe_lazy_row_live: per-listed-row switch for the NEXT lazy-Adam row-list call
+
+int kge_transe_lazy_row_live(const int32_t *d_row_live) { g_lazy_row_live = d_row_live; return KGE_OK; }
+
 int kge_transe_apply_rows_adam_lazy(const kge_model_desc *m, float *d_ent, float *d_rel, float *d_m_ent, float *d_m_rel, float *d_v_ent,
                                     float *d_v_rel, const int32_t *d_rows, const int32_t *d_row_counts, const int32_t *d_n_rows,
                                     INT max_rows, INT denom, float lr_t, float beta1, float beta2, float eps, void *stream_) {
@@ -1771,6 +1778,7 @@ int kge_transe_apply_rows_adam_lazy(const kge_model_desc *m, float *d_ent, float
     a.p = d_ent; a.p2 = d_rel; a.m = d_m_ent; a.m2 = d_m_rel; a.v = d_v_ent; a.v2 = d_v_rel;
     a.row_list = d_rows; a.S = const_cast<int32_t *>(d_row_counts); a.n_rows = d_n_rows;
     a.E = m->ent_total; a.D = m->ent_dim; a.unit = 1.0f / (float)denom; a.lr = lr_t; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.adam = 1;
+    a.row_live = g_lazy_row_live; g_lazy_row_live = nullptr;      // (one call only)
     const int D = m->ent_dim;
 #define KGE_RLAZY(LL, CC)                                                                                   \
     {                                                                                                       \

@@ -136,6 +136,23 @@ def test_ranks_sharded_sparse_table(tmp_path, world):
                 assert np.array_equal(r[k], one[k]), k
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_sharded_lazy_adam(tmp_path, world):
+    """opt_method "LazyAdam" (touched rows only; opt-in, non-parity against the reference's dense TF1 Adam) on N ranks: the entity
+    rows AND their two moment rows are sharded by row range (owner computes), the relation table and its moments stay replicated,
+    and a relation no rank had a record for keeps its row and moments.  Integer sums and one per-row update function: the union of
+    the shards after four steps equals the single-process table bit for bit (a wrong moment shard would show from the second step
+    on).  Reference for the optimizer choice: distribute_training.py:95-98."""
+    res = _run_worlds(tmp_path, [1, world], "TransE", "LazyAdam", True)
+    one = res[1][0]
+    for r in res[world]:
+        assert np.array_equal(r["states"], one["states"])
+        assert np.allclose(r["losses"], one["losses"], rtol=2e-5, atol=0)
+        for k in one.files:
+            if k not in ("losses", "states"):
+                assert np.array_equal(r[k], one[k]), k
+
+
 def test_two_ranks_with_prefetched_sampling(tmp_path):
     """The data-parallel default draws batch i+1 during step i's all-reduce: same tables as without."""
     import torch.multiprocessing as mp
@@ -459,7 +476,7 @@ def test_two_rank_step_against_the_oracle_full_batch_step(tmp_path, model_name, 
 
 
 @pytest.mark.parametrize("model_name,opt,sparse,pieces", [("TransE", "Adam", False, 2), ("TransE", "SGD", False, 0), ("TransH", "SGD", False, 2),
-                                                          ("TransR", "SGD", False, 0), ("TransE", "SGD", True, 0)])
+                                                          ("TransR", "SGD", False, 0), ("TransE", "SGD", True, 0), ("TransE", "LazyAdam", True, 0)])
 def test_one_rank_rccl_group_runs_the_data_parallel_step(tmp_path, model_name, opt, sparse, pieces):
     """The box has one GPU, so RCCL cannot run with two ranks here -- but it can run with ONE: `force_data_parallel` sends the
     step of a one-rank "nccl" process group through the whole exchange (asynchronous reduce-scatter of the count / gradient image
