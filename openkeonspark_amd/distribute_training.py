@@ -132,6 +132,10 @@ def checkpoint_arrays(con):
     runs (owner-kept Adam slots are gathered): every rank calls it, rank 0 writes.  A SHARDED entity table (the
     table-sharded sparse mode) is not gathered: every rank writes its own rows beside the main file (save_checkpoint)."""
     con.sync_optimizer_state()
+    if _sharded(con) and con._has_slots:
+        from ._lib import KgeError
+        raise KgeError("checkpoints of a table-sharded LazyAdam run are not written yet: the moment shards would have to travel with "
+                       "the row shards (train with --optimizer SGD on N ranks, or LazyAdam in one process, where checkpoints work)")
     if _sharded(con):
         out = {n: t.detach().cpu().numpy() for n, t in con.trainModel.parameter_lists.items() if n != "ent_embeddings"}
     else:
