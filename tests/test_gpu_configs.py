@@ -81,7 +81,7 @@ def check_sampled_batch(con, kg, B, n):
     return dev, bh, bt, br
 
 
-def run_steps(con, kg, orc, B, n, alpha, steps, name, model, dims, max_outside_rows=24):
+def run_steps(con, kg, orc, B, n, alpha, steps, name, model, dims, max_outside_rows=24, sampler_shaped=False):
     """`steps` SGD steps on device-sampled batches.  Every step the oracle starts from the ENGINE's current tables, so
     each comparison is of one forward/backward/update on identical inputs.  Rows outside 1e-5 must be explained: they
     have to be rows of a group in which some element of e = h^ + r^ - t^ lies within fp32 rounding of zero (fp64
@@ -98,7 +98,7 @@ def run_steps(con, kg, orc, B, n, alpha, steps, name, model, dims, max_outside_r
         hm = orc.hinge_margins(bh, bt, br, B, n)            # at the step's starting parameters (orc.params moves below)
         worst["ties"] += int((np.abs(hm) < 2e-6).sum())
         loss_o, g_o = orc.grad(bh, bt, br, B, n)
-        con.forward_backward(dev, B, B, B * n)
+        con.forward_backward(dev, B, B, B * n, sampler_shaped=sampler_shaped)      # (True: what train_step passes for a device-sampled batch)
         torch.cuda.synchronize()
         loss_g = float(con._loss.item())
         worst["loss"] = max(worst["loss"], abs(loss_g - loss_o) / abs(loss_o))
@@ -208,16 +208,27 @@ def test_pair_count_path_many_negatives(wn_dir, fb_dir, model, graph, nbatches, 
 # ------------------------------------------------------------------------------------------------------------------
 # configs[3]: FB15k-237-shaped TransR 200 x 200, tilings chosen by the engine
 # ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["fused relation tiles", "three kernels"])
 @pytest.mark.parametrize("nbatches,B", [(0, 2721), (8, 34014)])
-def test_config4_fb15k237_transr(fb_dir, nbatches, B):
+def test_config4_fb15k237_transr(fb_dir, nbatches, B, path):
+    """configs[3] at the reference's auto batch and at B = 34 014, device-sampled batches passed as such (what train_step does):
+    "fused relation tiles" = projection, vector stage and dgrad of a tile of groups in ONE kernel (csrc/transr.hip
+    fused_tile_kernel: 16 groups per workgroup at B = 2 721, 32 at B = 34 014 where dgrad's rows also go out as float records);
+    "three kernels" = the separate project / vector stage / dgrad launches.  Both against the oracle (TransR.py:16-75)."""
+    from openkeonspark_amd import _lib
     n, alpha = 1, 0.01
-    con = engine(fb_dir, "TransR", 200, nbatches, n, alpha)
-    assert (con.entTotal, con.relTotal, con.batch_size) == (14541, 237, B)
-    kg = oracle.KG(fb_dir, work_threads=8, bern=0)
-    kg.set_stream_states(con.get_stream_states())
-    orc = oracle.Model("transr", con.entTotal, con.relTotal, 200, 200, margin=1.0, params=con.get_parameters())
-    # B = 34 014: relations with >= 256 rows take the all-output-tiles wgrad, the skewed rest the 32-row tiles (transr.hip)
-    run_steps(con, kg, orc, B, n, alpha, steps=2, name="config4 FB15k-237 TransR 200x200 B=%d" % B, model="transr", dims=(200, 200))
+    _lib.lib().kge_set_option(b"transr_fused", 1 if path.startswith("fused") else 0)
+    try:
+        con = engine(fb_dir, "TransR", 200, nbatches, n, alpha)
+        assert (con.entTotal, con.relTotal, con.batch_size) == (14541, 237, B)
+        kg = oracle.KG(fb_dir, work_threads=8, bern=0)
+        kg.set_stream_states(con.get_stream_states())
+        orc = oracle.Model("transr", con.entTotal, con.relTotal, 200, 200, margin=1.0, params=con.get_parameters())
+        # B = 34 014: relations with >= 256 rows take the all-output-tiles wgrad, the skewed rest the 32-row tiles (transr.hip)
+        run_steps(con, kg, orc, B, n, alpha, steps=2, name="config4 FB15k-237 TransR 200x200 B=%d (%s)" % (B, path), model="transr", dims=(200, 200),
+                  sampler_shaped=True)
+    finally:
+        _lib.lib().kge_set_option(b"transr_fused", 1)
 
 
 # ------------------------------------------------------------------------------------------------------------------
