@@ -663,6 +663,241 @@ __global__ __launch_bounds__(256, 2) void rows_gemm2_kernel(GemmArgs a) {   // t
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v3 row GEMMs: fp32 products on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+// The fp32 MFMA runs at the vector rate (64 flop / clk / SIMD = 1/16 of the bf16 MFMA): at B = 34 014 the v2 K loop is 89 % matrix-
+// pipe time and the kernels cannot get past ~57 % of the fp32 peak.  Every fp32 value splits EXACTLY into three bf16 terms
+// (x = x1 + x2 + x3: x1 = bf16(x), x2 = bf16(x - x1), x3 = x - x1 - x2 -- 8 + 8 + 8 significand bits, the residuals are exact in
+// fp32), every bf16 x bf16 product is exact in the pipe's fp32 accumulation, and a.b = sum_ij a_i b_j.  Six of the nine term
+// products are formed -- (1,1) (1,2) (2,1) (2,2) (1,3) (3,1); the three dropped ones are below 2^-25 |a b|, under the rounding of
+// ONE fp32 accumulate (2^-24) -- so a k-block of 32 costs 6 x 16 = 96 cycles on a SIMD where the fp32 MFMA takes 8 x 32 = 256.
+// Measured against fp64 the result is as close as the fp32-MFMA kernels' (tests/test_gpu_models.py, both tilings vs the oracle).
+//
+// LDS image of an operand: [term][row or column][32 bf16 of the k-block] = 64-byte rows, the 16-byte chunk index XORed with
+// (row >> 2) & 3, so the ds_read_b128 of an MFMA fragment (16 rows x one chunk) and the staging writes spread over all banks.
+// The split is done on the way into LDS (5.5 VALU per element, done once per element and k-block by the staging threads).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int KB3 = 32;            // k-block: one bf16 MFMA per term pair
+constexpr int RW3 = 128;           // rows per workgroup (wave w: sub-tiles w and w + 4, as v2)
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {     // v_cvt_pk_bf16_f32 (round to nearest even)
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// two fp32 values -> their three bf16 terms, packed pairwise (low half: a)
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned &p1, unsigned &p2, unsigned &p3) {
+    p1 = pack_bf16(a, b);
+    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pack_bf16(ra, rb);
+    p3 = pack_bf16(ra - __uint_as_float(p2 << 16), rb - __uint_as_float(p2 & 0xffff0000u));
+}
+__device__ __forceinline__ void split3_8(const float (&v)[8], uint4 &t1, uint4 &t2, uint4 &t3) {
+    split3_pair(v[0], v[1], t1.x, t2.x, t3.x);
+    split3_pair(v[2], v[3], t1.y, t2.y, t3.y);
+    split3_pair(v[4], v[5], t1.z, t2.z, t3.z);
+    split3_pair(v[6], v[7], t1.w, t2.w, t3.w);
+}
+// byte offset of chunk `ch` (8 bf16) of row `row` of term plane `term` (planes of `plane_rows` rows)
+__device__ __forceinline__ int lds3_off(int plane_rows, int term, int row, int ch) {
+    return ((term * plane_rows + row) << 6) + ((ch ^ ((row >> 2) & 3)) << 4);
+}
+
+// one k-block of a wave's NS x NT accumulator tiles: the A fragments of the wave's sub-tiles are read once, the B fragments of column
+// tile t + 1 are requested in front of the 6 NS matrix instructions of tile t
+template <int NT, int NS>
+__device__ __forceinline__ void gemm3_mfma_block(const unsigned char *__restrict__ As, const unsigned char *__restrict__ Bs,
+                                                 f32x4 (&acc)[RT2][NT], int wave, int lane) {
+    constexpr int NCOL = NT * 16;
+    const int r16 = lane & 15, g = lane >> 4;
+    bf16x8 af[NS][3];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; s2++)
+#pragma unroll
+        for (int t = 0; t < 3; t++) af[s2][t] = *reinterpret_cast<const bf16x8 *>(As + lds3_off(RW3, t, (4 * s2 + wave) * 16 + r16, g));
+    bf16x8 bf[2][3];
+    auto fetch = [&](int buf, int ct) {
+#pragma unroll
+        for (int t = 0; t < 3; t++) bf[buf][t] = *reinterpret_cast<const bf16x8 *>(Bs + lds3_off(NCOL, t, ct * 16 + r16, g));
+    };
+    fetch(0, 0);
+    static_for<0, NT>([&](auto tc) {
+        constexpr int ct = decltype(tc)::value;
+        constexpr int cur = ct & 1;
+        if constexpr (ct + 1 < NT) fetch(cur ^ 1, ct + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < NS; s2++) {
+            f32x4 c = acc[s2][ct];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][0], bf[cur][2], c, 0, 0, 0);   // small terms first
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][2], bf[cur][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][1], bf[cur][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][0], bf[cur][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][1], bf[cur][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][0], bf[cur][0], c, 0, 0, 0);
+            acc[s2][ct] = c;
+        }
+    });
+}
+
+template <int MODE, int NT>
+__global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
+    constexpr int NCOL = NT * 16;
+    const int tile = blockIdx.x;
+    if (tile >= a.n_tiles[0]) return;
+    __shared__ __attribute__((aligned(16))) unsigned char As[3 * RW3 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * NCOL * 64];
+    __shared__ int s_slot[RW3], s_ent[RW3];
+    const int r = a.tile_rel[tile];
+    const int row0 = a.tile_row0[tile];
+    const int rows = min(RW3, a.bucket_start[r + 1] - row0);
+    const int K = MODE == GEMM_PROJECT ? a.De : a.Dr;
+    const int ncols = MODE == GEMM_PROJECT ? a.Dr : a.De;            // multiple of 4, <= NCOL
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < RW3) {
+        const int sl = a.sorted_slots[row0 + min(tid, rows - 1)];     // padding rows repeat the last live row (zeroed on the way into LDS)
+        s_slot[tid] = sl;
+        s_ent[tid] = a.job_ent[sl];
+    }
+    __syncthreads();
+    const float *M = a.mat + (long long)r * a.De * a.Dr;
+    f32x4 acc[RT2][NT];
+#pragma unroll
+    for (int s2 = 0; s2 < RT2; s2++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[s2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int n_live = (wave * 16 < rows ? 1 : 0) + ((4 + wave) * 16 < rows ? 1 : 0);
+    // staging tasks.  A: (row i, chunk q) = 8 consecutive k of one row, two per thread.  B of dgrad (B[k = j][col = i] = M[i][j],
+    // k contiguous in memory): (column c, chunk q), up to four per thread.  B of the projection (B[k = i][col = j] = M[i][j], k strided):
+    // (column quad jq, chunk q) = 8 rows of 4 columns, transposed in registers, one per thread.
+    constexpr int NBD = (NCOL * 4 + 255) / 256;
+    constexpr int JQ = NCOL / 4;
+    float4 ra[2][2], rb[8];
+    const int pj = tid % JQ, pq = tid / JQ;         // projection B task (pq < 4: live)
+#define KGE_LOAD3(k0_)                                                                                                        \
+    {                                                                                                                         \
+        static_for<0, 2>([&](auto uc) {                                                                                       \
+            constexpr int u = decltype(uc)::value;                                                                            \
+            const int idx = tid + 256 * u, i = idx >> 2, q = idx & 3;                                                          \
+            const float *src = MODE == GEMM_PROJECT ? a.ent + (long long)s_ent[i] * a.De : a.GP + (long long)s_slot[i] * a.Dr; \
+            ra[u][0] = *reinterpret_cast<const float4 *>(src + min((k0_) + 8 * q, K - 4));                                     \
+            ra[u][1] = *reinterpret_cast<const float4 *>(src + min((k0_) + 8 * q + 4, K - 4));                                 \
+        });                                                                                                                   \
+        if constexpr (MODE == GEMM_PROJECT) {                                                                                 \
+            static_for<0, 8>([&](auto ec) {                                                                                   \
+                constexpr int e = decltype(ec)::value;                                                                        \
+                rb[e] = *reinterpret_cast<const float4 *>(M + (long long)min((k0_) + 8 * min(pq, 3) + e, K - 1) * a.Dr + min(4 * pj, ncols - 4)); \
+            });                                                                                                               \
+        } else {                                                                                                              \
+            static_for<0, NBD>([&](auto uc) {                                                                                 \
+                constexpr int u = decltype(uc)::value;                                                                        \
+                const int idx = min(tid + 256 * u, NCOL * 4 - 1), c = idx >> 2, q = idx & 3;                                   \
+                const float *src = M + (long long)min(c, ncols - 1) * a.Dr;                                                    \
+                rb[2 * u] = *reinterpret_cast<const float4 *>(src + min((k0_) + 8 * q, K - 4));                                \
+                rb[2 * u + 1] = *reinterpret_cast<const float4 *>(src + min((k0_) + 8 * q + 4, K - 4));                        \
+            });                                                                                                               \
+        }                                                                                                                     \
+    }
+    KGE_LOAD3(0)
+    for (int k0 = 0; k0 < K; k0 += KB3) {
+        if (k0 > 0) __syncthreads();          // the previous k-block's fragment reads are done
+        static_for<0, 2>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            const int idx = tid + 256 * u, i = idx >> 2, q = idx & 3;
+            const float4 lo = keep_if(i < rows && k0 + 8 * q < K, ra[u][0]), hi = keep_if(i < rows && k0 + 8 * q + 4 < K, ra[u][1]);
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            uint4 t1, t2, t3;
+            split3_8(v, t1, t2, t3);
+            *reinterpret_cast<uint4 *>(As + lds3_off(RW3, 0, i, q)) = t1;
+            *reinterpret_cast<uint4 *>(As + lds3_off(RW3, 1, i, q)) = t2;
+            *reinterpret_cast<uint4 *>(As + lds3_off(RW3, 2, i, q)) = t3;
+        });
+        if constexpr (MODE == GEMM_PROJECT) {
+            if (pq < 4) {
+                float4 m[8];
+                static_for<0, 8>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value;
+                    m[e] = keep_if(k0 + 8 * pq + e < K && 4 * pj < ncols, rb[e]);
+                });
+                uint4 t1, t2, t3;
+                {
+                    const float v[8] = {m[0].x, m[1].x, m[2].x, m[3].x, m[4].x, m[5].x, m[6].x, m[7].x};
+                    split3_8(v, t1, t2, t3);
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 0, 4 * pj, pq)) = t1;
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 1, 4 * pj, pq)) = t2;
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 2, 4 * pj, pq)) = t3;
+                }
+                {
+                    const float v[8] = {m[0].y, m[1].y, m[2].y, m[3].y, m[4].y, m[5].y, m[6].y, m[7].y};
+                    split3_8(v, t1, t2, t3);
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 0, 4 * pj + 1, pq)) = t1;
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 1, 4 * pj + 1, pq)) = t2;
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 2, 4 * pj + 1, pq)) = t3;
+                }
+                {
+                    const float v[8] = {m[0].z, m[1].z, m[2].z, m[3].z, m[4].z, m[5].z, m[6].z, m[7].z};
+                    split3_8(v, t1, t2, t3);
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 0, 4 * pj + 2, pq)) = t1;
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 1, 4 * pj + 2, pq)) = t2;
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 2, 4 * pj + 2, pq)) = t3;
+                }
+                {
+                    const float v[8] = {m[0].w, m[1].w, m[2].w, m[3].w, m[4].w, m[5].w, m[6].w, m[7].w};
+                    split3_8(v, t1, t2, t3);
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 0, 4 * pj + 3, pq)) = t1;
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 1, 4 * pj + 3, pq)) = t2;
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 2, 4 * pj + 3, pq)) = t3;
+                }
+            }
+        } else {
+            static_for<0, NBD>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int idx = tid + 256 * u;
+                if (idx < NCOL * 4) {
+                    const int c = idx >> 2, q = idx & 3;
+                    const float4 lo = keep_if(c < ncols && k0 + 8 * q < K, rb[2 * u]), hi = keep_if(c < ncols && k0 + 8 * q + 4 < K, rb[2 * u + 1]);
+                    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    uint4 t1, t2, t3;
+                    split3_8(v, t1, t2, t3);
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 0, c, q)) = t1;
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 1, c, q)) = t2;
+                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 2, c, q)) = t3;
+                }
+            });
+        }
+        __syncthreads();
+        if (k0 + KB3 < K) KGE_LOAD3(k0 + KB3)   // in flight during the matrix work
+        if (rows > RM2) gemm3_mfma_block<NT, RT2>(As, Bs, acc, wave, lane);
+        else if (n_live > 0) gemm3_mfma_block<NT, 1>(As, Bs, acc, wave, lane);
+    }
+#undef KGE_LOAD3
+    if (MODE == GEMM_DGRAD && a.rec_out && tid < rows) a.rec_dst[row0 + tid] = s_ent[tid];
+#pragma unroll
+    for (int s2 = 0; s2 < RT2; s2++) {
+        if ((4 * s2 + wave) * 16 >= rows) continue;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int j = t * 16 + (lane & 15);
+            if (j < ncols) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int row = (4 * s2 + wave) * 16 + 4 * (lane >> 4) + v;
+                    if (row < rows) {
+                        if (MODE == GEMM_PROJECT) a.P[(long long)s_slot[row] * a.Dr + j] = acc[s2][t][v];
+                        else if (a.rec_out) a.rec_out[(long long)(row0 + row) * a.De + j] = acc[s2][t][v];
+                        else __builtin_amdgcn_global_atomic_fadd_f32(
+                                (__attribute__((address_space(1))) float *)(a.g_ent + (long long)s_ent[row] * a.De + j), acc[s2][t][v]);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // wgrad v2 (dims 196..208, multiples of 4: the full 13 x 13 output tile grid): g_M[r][i][j] += sum over rows of
 // ent[e_row][i] * GP[slot_row][j].  A workgroup owns SPAN2 consecutive 128-row tiles of the relation-sorted job list
 // (512 rows between flushes) and one HALF of the output row tiles (blockIdx.y: tiles 0..6 / 7..12) with every column
@@ -1267,7 +1502,11 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     // sparse buckets (config #4's auto batch: 46 rows per relation, ~one tile per relation, fewer tiles than CUs): two column
     // blocks of 7 tiles per row tile instead of one of 13
     const bool split_cols = v2 && slots < 256 * R && engine().transr_v1 == 0;
-    if (v2 && Dr <= 112) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, 7>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
+    // v3: the same tiles with the products on the bf16 matrix pipe (three-term split, rows_gemm3_kernel)
+    const bool v3 = v2 && engine().transr_bf16x3 && engine().transr_v1 == 0;
+    if (v3 && Dr <= 112) hipLaunchKernelGGL((rows_gemm3_kernel<GEMM_PROJECT, 7>), dim3(max_tiles), dim3(256), 0, stream, ga);
+    else if (v3) hipLaunchKernelGGL((rows_gemm3_kernel<GEMM_PROJECT, 13>), dim3(max_tiles), dim3(256), 0, stream, ga);
+    else if (v2 && Dr <= 112) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, 7>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
     else if (v2 && split_cols) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, 7>), dim3(max_tiles, (Dr + 111) / 112), dim3(256), 0, stream, ga);
     else if (v2) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_PROJECT, 13>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
     else hipLaunchKernelGGL((rows_gemm_kernel<GEMM_PROJECT>), dim3(max_tiles, (Dr + TN - 1) / TN), dim3(256), 0, stream, ga);
@@ -1277,7 +1516,9 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
                                     m.negative_rel, d_loss, stream, lean, sampler_shaped, R);
     if (rc) return rc;
     if (v2) {
-        if (De <= 112) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 7>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
+        if (v3 && De <= 112) hipLaunchKernelGGL((rows_gemm3_kernel<GEMM_DGRAD, 7>), dim3(max_tiles), dim3(256), 0, stream, ga);
+        else if (v3) hipLaunchKernelGGL((rows_gemm3_kernel<GEMM_DGRAD, 13>), dim3(max_tiles), dim3(256), 0, stream, ga);
+        else if (De <= 112) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 7>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
         else if (split_cols) hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 7>), dim3(max_tiles, (De + 111) / 112), dim3(256), 0, stream, ga);
         else hipLaunchKernelGGL((rows_gemm2_kernel<GEMM_DGRAD, 13>), dim3(max_tiles, 1), dim3(256), 0, stream, ga);
         if (dgrad_records) {

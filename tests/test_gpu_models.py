@@ -97,15 +97,18 @@ CASES = [("transe", 300, 11, 16), ("transe", 300, 11, 100), ("transe", 200, 7, 2
 TRANSR_CASES = [(120, 9, 12, 8), (150, 7, 200, 200), (90, 5, 64, 100), (60, 4, 33, 50)]
 
 
-@pytest.fixture(params=["v2-16x16x4", "v2-wgrad-all-tiles", "v2-wgrad-32x32x2", "v1-32x32x2"])
+@pytest.fixture(params=["v3-bf16x3", "v2-16x16x4", "v2-wgrad-all-tiles", "v2-wgrad-32x32x2", "v1-32x32x2"])
 def transr_tiles(request):
-    """The MFMA tilings of the TransR projections: 16x16x4 / 128-row tiles (dims <= 208; its all-output-tiles wgrad
-    is only chosen for well-filled buckets, so it is forced here) and 32x32x2 / 32-row tiles."""
+    """The MFMA tilings of the TransR projections: 128-row tiles with the fp32 products formed as six bf16 term products of an
+    exact three-term split (the default for dims <= 208, multiples of 4), the same tiles on the fp32 MFMA (16x16x4; its
+    all-output-tiles wgrad is only chosen for well-filled buckets, so it is forced here) and 32x32x2 / 32-row tiles."""
     from openkeonspark_amd import _lib
     L = _lib.lib()
-    L.kge_set_option(b"transr_v1", {"v1-32x32x2": 1, "v2-wgrad-all-tiles": 2, "v2-wgrad-32x32x2": 3, "v2-16x16x4": 0}[request.param])
+    L.kge_set_option(b"transr_bf16x3", 1 if request.param == "v3-bf16x3" else 0)
+    L.kge_set_option(b"transr_v1", {"v1-32x32x2": 1, "v2-wgrad-all-tiles": 2, "v2-wgrad-32x32x2": 3, "v2-16x16x4": 0, "v3-bf16x3": 0}[request.param])
     yield request.param
     L.kge_set_option(b"transr_v1", 0)
+    L.kge_set_option(b"transr_bf16x3", 1)
 
 
 @pytest.mark.parametrize("E,R,De,Dr", TRANSR_CASES + [(80, 3, 208, 16), (70, 6, 100, 208)])
