@@ -706,18 +706,12 @@ __device__ __forceinline__ int lds3_off(int plane_rows, int term, int row, int c
     return ((term * plane_rows + row) << 6) + ((ch ^ ((row >> 2) & 3)) << 4);
 }
 
-// one k-block of a wave's NS x NT accumulator tiles: the A fragments of the wave's sub-tiles are read once, the B fragments of column
-// tile t + 1 are requested in front of the 6 NS matrix instructions of tile t
+// one k-block of a wave's NS x NT accumulator tiles: the A fragments are in registers (af), the B fragments of column tile t + 1 are
+// requested in front of the 6 NS matrix instructions of tile t
 template <int NT, int NS>
-__device__ __forceinline__ void gemm3_mfma_block(const unsigned char *__restrict__ As, const unsigned char *__restrict__ Bs,
-                                                 f32x4 (&acc)[RT2][NT], int wave, int lane) {
+__device__ __forceinline__ void gemm3_mfma_block(const bf16x8 (&af)[RT2][3], const unsigned char *__restrict__ Bs, f32x4 (&acc)[RT2][NT], int lane) {
     constexpr int NCOL = NT * 16;
     const int r16 = lane & 15, g = lane >> 4;
-    bf16x8 af[NS][3];
-#pragma unroll
-    for (int s2 = 0; s2 < NS; s2++)
-#pragma unroll
-        for (int t = 0; t < 3; t++) af[s2][t] = *reinterpret_cast<const bf16x8 *>(As + lds3_off(RW3, t, (4 * s2 + wave) * 16 + r16, g));
     bf16x8 bf[2][3];
     auto fetch = [&](int buf, int ct) {
 #pragma unroll
@@ -743,13 +737,24 @@ __device__ __forceinline__ void gemm3_mfma_block(const unsigned char *__restrict
     });
 }
 
+// Structure of a workgroup (128 rows of one relation x all output columns, four waves, wave w: rows 16 w .. and 64 + 16 w ..):
+//  * the A operand never touches LDS: a lane of a 16x16x32 fragment holds 8 consecutive k of ONE row, and a wave's rows are its
+//    own, so every lane reads its 32 bytes straight from the gathered row (ent / GP), one k-block ahead, and splits them in
+//    registers;
+//  * the B operand (the relation's matrix, shared by the four waves) is split on the way into a DOUBLE-buffered LDS image: one
+//    barrier per k-block, the image of block k + 1 is written while other waves still multiply block k, its global loads were
+//    issued a whole k-block earlier;
+//  * the output tile goes back through LDS (each wave its own 16 rows) so that every row leaves as one contiguous run of float4.
+// Rows beyond the tile's live rows and k beyond K need no masking on the A side: B is zero for k >= K, A reads are clamped to valid
+// finite data, and the output rows / columns of the padding are never stored.
 template <int MODE, int NT>
 __global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
     constexpr int NCOL = NT * 16;
+    constexpr int BIMG = 3 * NCOL * 64;      // bytes of one B image
+    constexpr int LDC = NCOL + 4;            // output staging row (floats): 4 (mod 8), the transposing writes of a half-wave hit 32 banks
     const int tile = blockIdx.x;
     if (tile >= a.n_tiles[0]) return;
-    __shared__ __attribute__((aligned(16))) unsigned char As[3 * RW3 * 64];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * NCOL * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * BIMG];
     __shared__ int s_slot[RW3], s_ent[RW3];
     const int r = a.tile_rel[tile];
     const int row0 = a.tile_row0[tile];
@@ -758,35 +763,16 @@ __global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
     const int ncols = MODE == GEMM_PROJECT ? a.Dr : a.De;            // multiple of 4, <= NCOL
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < RW3) {
-        const int sl = a.sorted_slots[row0 + min(tid, rows - 1)];     // padding rows repeat the last live row (zeroed on the way into LDS)
-        s_slot[tid] = sl;
-        s_ent[tid] = a.job_ent[sl];
-    }
-    __syncthreads();
+    const int r16 = lane & 15, g = lane >> 4;
     const float *M = a.mat + (long long)r * a.De * a.Dr;
-    f32x4 acc[RT2][NT];
-#pragma unroll
-    for (int s2 = 0; s2 < RT2; s2++)
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[s2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int n_live = (wave * 16 < rows ? 1 : 0) + ((4 + wave) * 16 < rows ? 1 : 0);
-    // staging tasks.  A: (row i, chunk q) = 8 consecutive k of one row, two per thread.  B of dgrad (B[k = j][col = i] = M[i][j],
-    // k contiguous in memory): (column c, chunk q), up to four per thread.  B of the projection (B[k = i][col = j] = M[i][j], k strided):
-    // (column quad jq, chunk q) = 8 rows of 4 columns, transposed in registers, one per thread.
+    // B staging tasks.  dgrad (B[k = j][col = i] = M[i][j], k contiguous in memory): (column c, chunk q), up to four per thread.
+    // Projection (B[k = i][col = j] = M[i][j], k strided): (column quad jq, chunk q) = 8 rows of 4 columns, transposed in registers.
     constexpr int NBD = (NCOL * 4 + 255) / 256;
     constexpr int JQ = NCOL / 4;
-    float4 ra[2][2], rb[8];
+    float4 rb[8];
     const int pj = tid % JQ, pq = tid / JQ;         // projection B task (pq < 4: live)
-#define KGE_LOAD3(k0_)                                                                                                        \
+#define KGE_LOADB3(k0_)                                                                                                       \
     {                                                                                                                         \
-        static_for<0, 2>([&](auto uc) {                                                                                       \
-            constexpr int u = decltype(uc)::value;                                                                            \
-            const int idx = tid + 256 * u, i = idx >> 2, q = idx & 3;                                                          \
-            const float *src = MODE == GEMM_PROJECT ? a.ent + (long long)s_ent[i] * a.De : a.GP + (long long)s_slot[i] * a.Dr; \
-            ra[u][0] = *reinterpret_cast<const float4 *>(src + min((k0_) + 8 * q, K - 4));                                     \
-            ra[u][1] = *reinterpret_cast<const float4 *>(src + min((k0_) + 8 * q + 4, K - 4));                                 \
-        });                                                                                                                   \
         if constexpr (MODE == GEMM_PROJECT) {                                                                                 \
             static_for<0, 8>([&](auto ec) {                                                                                   \
                 constexpr int e = decltype(ec)::value;                                                                        \
@@ -802,56 +788,26 @@ __global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
             });                                                                                                               \
         }                                                                                                                     \
     }
-    KGE_LOAD3(0)
-    for (int k0 = 0; k0 < K; k0 += KB3) {
-        if (k0 > 0) __syncthreads();          // the previous k-block's fragment reads are done
-        static_for<0, 2>([&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            const int idx = tid + 256 * u, i = idx >> 2, q = idx & 3;
-            const float4 lo = keep_if(i < rows && k0 + 8 * q < K, ra[u][0]), hi = keep_if(i < rows && k0 + 8 * q + 4 < K, ra[u][1]);
-            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            uint4 t1, t2, t3;
-            split3_8(v, t1, t2, t3);
-            *reinterpret_cast<uint4 *>(As + lds3_off(RW3, 0, i, q)) = t1;
-            *reinterpret_cast<uint4 *>(As + lds3_off(RW3, 1, i, q)) = t2;
-            *reinterpret_cast<uint4 *>(As + lds3_off(RW3, 2, i, q)) = t3;
-        });
+#define KGE_PUTB3(col_, ch_, v_)                                                                                              \
+    {                                                                                                                         \
+        uint4 t1, t2, t3;                                                                                                     \
+        split3_8(v_, t1, t2, t3);                                                                                             \
+        *reinterpret_cast<uint4 *>(img + lds3_off(NCOL, 0, (col_), (ch_))) = t1;                                              \
+        *reinterpret_cast<uint4 *>(img + lds3_off(NCOL, 1, (col_), (ch_))) = t2;                                              \
+        *reinterpret_cast<uint4 *>(img + lds3_off(NCOL, 2, (col_), (ch_))) = t3;                                              \
+    }
+    auto store_b = [&](unsigned char *img, int k0) {
         if constexpr (MODE == GEMM_PROJECT) {
             if (pq < 4) {
                 float4 m[8];
                 static_for<0, 8>([&](auto ec) {
                     constexpr int e = decltype(ec)::value;
-                    m[e] = keep_if(k0 + 8 * pq + e < K && 4 * pj < ncols, rb[e]);
+                    m[e] = keep_if(k0 + 8 * pq + e < K, rb[e]);
                 });
-                uint4 t1, t2, t3;
-                {
-                    const float v[8] = {m[0].x, m[1].x, m[2].x, m[3].x, m[4].x, m[5].x, m[6].x, m[7].x};
-                    split3_8(v, t1, t2, t3);
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 0, 4 * pj, pq)) = t1;
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 1, 4 * pj, pq)) = t2;
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 2, 4 * pj, pq)) = t3;
-                }
-                {
-                    const float v[8] = {m[0].y, m[1].y, m[2].y, m[3].y, m[4].y, m[5].y, m[6].y, m[7].y};
-                    split3_8(v, t1, t2, t3);
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 0, 4 * pj + 1, pq)) = t1;
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 1, 4 * pj + 1, pq)) = t2;
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 2, 4 * pj + 1, pq)) = t3;
-                }
-                {
-                    const float v[8] = {m[0].z, m[1].z, m[2].z, m[3].z, m[4].z, m[5].z, m[6].z, m[7].z};
-                    split3_8(v, t1, t2, t3);
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 0, 4 * pj + 2, pq)) = t1;
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 1, 4 * pj + 2, pq)) = t2;
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 2, 4 * pj + 2, pq)) = t3;
-                }
-                {
-                    const float v[8] = {m[0].w, m[1].w, m[2].w, m[3].w, m[4].w, m[5].w, m[6].w, m[7].w};
-                    split3_8(v, t1, t2, t3);
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 0, 4 * pj + 3, pq)) = t1;
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 1, 4 * pj + 3, pq)) = t2;
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 2, 4 * pj + 3, pq)) = t3;
-                }
+                { const float v[8] = {m[0].x, m[1].x, m[2].x, m[3].x, m[4].x, m[5].x, m[6].x, m[7].x}; KGE_PUTB3(4 * pj, pq, v) }
+                { const float v[8] = {m[0].y, m[1].y, m[2].y, m[3].y, m[4].y, m[5].y, m[6].y, m[7].y}; KGE_PUTB3(4 * pj + 1, pq, v) }
+                { const float v[8] = {m[0].z, m[1].z, m[2].z, m[3].z, m[4].z, m[5].z, m[6].z, m[7].z}; KGE_PUTB3(4 * pj + 2, pq, v) }
+                { const float v[8] = {m[0].w, m[1].w, m[2].w, m[3].w, m[4].w, m[5].w, m[6].w, m[7].w}; KGE_PUTB3(4 * pj + 3, pq, v) }
             }
         } else {
             static_for<0, NBD>([&](auto uc) {
@@ -859,42 +815,123 @@ __global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
                 const int idx = tid + 256 * u;
                 if (idx < NCOL * 4) {
                     const int c = idx >> 2, q = idx & 3;
-                    const float4 lo = keep_if(c < ncols && k0 + 8 * q < K, rb[2 * u]), hi = keep_if(c < ncols && k0 + 8 * q + 4 < K, rb[2 * u + 1]);
+                    const float4 lo = keep_if(k0 + 8 * q < K, rb[2 * u]), hi = keep_if(k0 + 8 * q + 4 < K, rb[2 * u + 1]);
                     const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    uint4 t1, t2, t3;
-                    split3_8(v, t1, t2, t3);
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 0, c, q)) = t1;
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 1, c, q)) = t2;
-                    *reinterpret_cast<uint4 *>(Bs + lds3_off(NCOL, 2, c, q)) = t3;
+                    KGE_PUTB3(c, q, v)
                 }
             });
         }
-        __syncthreads();
-        if (k0 + KB3 < K) KGE_LOAD3(k0 + KB3)   // in flight during the matrix work
-        if (rows > RM2) gemm3_mfma_block<NT, RT2>(As, Bs, acc, wave, lane);
-        else if (n_live > 0) gemm3_mfma_block<NT, 1>(As, Bs, acc, wave, lane);
+    };
+    KGE_LOADB3(0)            // the matrix does not depend on the index chain below
+    if (tid < RW3) {
+        const int sl = a.sorted_slots[row0 + min(tid, rows - 1)];     // padding rows repeat the last live row (never stored)
+        s_slot[tid] = sl;
+        s_ent[tid] = a.job_ent[sl];
     }
-#undef KGE_LOAD3
-    if (MODE == GEMM_DGRAD && a.rec_out && tid < rows) a.rec_dst[row0 + tid] = s_ent[tid];
+    __syncthreads();
+    const float *arow[RT2];
 #pragma unroll
     for (int s2 = 0; s2 < RT2; s2++) {
-        if ((4 * s2 + wave) * 16 >= rows) continue;
+        const int row = (4 * s2 + wave) * 16 + r16;
+        arow[s2] = MODE == GEMM_PROJECT ? a.ent + (long long)s_ent[row] * a.De : a.GP + (long long)s_slot[row] * a.Dr;
+    }
+    const bool two = rows > RM2;                                       // (workgroup-uniform) second sub-tiles exist
+    const bool live = wave * 16 < rows;                                // this wave has rows at all
+    float4 ra[RT2][2];
+#define KGE_LOADA3(k0_)                                                                                                       \
+    {                                                                                                                         \
+        ra[0][0] = *reinterpret_cast<const float4 *>(arow[0] + min((k0_) + 8 * g, K - 4));                                     \
+        ra[0][1] = *reinterpret_cast<const float4 *>(arow[0] + min((k0_) + 8 * g + 4, K - 4));                                 \
+        if (two) {                                                                                                            \
+            ra[1][0] = *reinterpret_cast<const float4 *>(arow[1] + min((k0_) + 8 * g, K - 4));                                 \
+            ra[1][1] = *reinterpret_cast<const float4 *>(arow[1] + min((k0_) + 8 * g + 4, K - 4));                             \
+        }                                                                                                                     \
+    }
+    KGE_LOADA3(0)
+    f32x4 acc[RT2][NT];
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const int j = t * 16 + (lane & 15);
-            if (j < ncols) {
+    for (int s2 = 0; s2 < RT2; s2++)
 #pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const int row = (4 * s2 + wave) * 16 + 4 * (lane >> 4) + v;
-                    if (row < rows) {
-                        if (MODE == GEMM_PROJECT) a.P[(long long)s_slot[row] * a.Dr + j] = acc[s2][t][v];
-                        else if (a.rec_out) a.rec_out[(long long)(row0 + row) * a.De + j] = acc[s2][t][v];
-                        else __builtin_amdgcn_global_atomic_fadd_f32(
+        for (int t = 0; t < NT; t++) acc[s2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    store_b(Bs, 0);
+    if (KB3 < K) KGE_LOADB3(KB3)
+    __syncthreads();
+    int kb = 0;
+    for (int k0 = 0; k0 < K; k0 += KB3, kb ^= 1) {
+        const bool more = k0 + KB3 < K;
+        bf16x8 af[RT2][3];
+#pragma unroll
+        for (int s2 = 0; s2 < RT2; s2++) {
+            if (s2 == 0 || two) {
+                const float v[8] = {ra[s2][0].x, ra[s2][0].y, ra[s2][0].z, ra[s2][0].w, ra[s2][1].x, ra[s2][1].y, ra[s2][1].z, ra[s2][1].w};
+                uint4 t1, t2, t3;
+                split3_8(v, t1, t2, t3);
+                af[s2][0] = __builtin_bit_cast(bf16x8, t1); af[s2][1] = __builtin_bit_cast(bf16x8, t2); af[s2][2] = __builtin_bit_cast(bf16x8, t3);
+            } else {
+                af[s2][0] = af[0][0]; af[s2][1] = af[0][1]; af[s2][2] = af[0][2];      // (13-tile instantiation: multiplied, never stored)
+            }
+        }
+        if (more) KGE_LOADA3(k0 + KB3)                  // in flight during this block's matrix work
+        if constexpr (NT <= 7) {
+            if (two) gemm3_mfma_block<NT, RT2>(af, Bs + kb * BIMG, acc, lane);
+            else if (live) gemm3_mfma_block<NT, 1>(af, Bs + kb * BIMG, acc, lane);
+        } else {
+            if (live) gemm3_mfma_block<NT, RT2>(af, Bs + kb * BIMG, acc, lane);
+        }
+        if (more) {
+            store_b(Bs + (kb ^ 1) * BIMG, k0 + KB3);   // (that image was last read before the previous barrier)
+            if (k0 + 2 * KB3 < K) KGE_LOADB3(k0 + 2 * KB3)
+        }
+        __syncthreads();
+    }
+#undef KGE_LOADA3
+#undef KGE_LOADB3
+#undef KGE_PUTB3
+    if (MODE == GEMM_DGRAD && a.rec_out && tid < rows) a.rec_dst[row0 + tid] = s_ent[tid];
+    if (MODE == GEMM_DGRAD && !a.rec_out) {            // small steps: fp32 atomics straight from the accumulators
+#pragma unroll
+        for (int s2 = 0; s2 < RT2; s2++) {
+            if ((4 * s2 + wave) * 16 >= rows) continue;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const int j = t * 16 + r16;
+                if (j < ncols) {
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const int row = (4 * s2 + wave) * 16 + 4 * g + v;
+                        if (row < rows) __builtin_amdgcn_global_atomic_fadd_f32(
                                 (__attribute__((address_space(1))) float *)(a.g_ent + (long long)s_ent[row] * a.De + j), acc[s2][t][v]);
                     }
                 }
             }
         }
+        return;
+    }
+    // rows out through LDS (the B images are free: every wave is past the last barrier): wave-private 16 x LDC staging
+    float *Cs = reinterpret_cast<float *>(Bs) + wave * 16 * LDC;
+    const int qn = ncols >> 2;
+#pragma unroll
+    for (int s2 = 0; s2 < RT2; s2++) {
+        const int base = (4 * s2 + wave) * 16;
+        if (base >= rows) continue;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) Cs[(4 * g + v) * LDC + 16 * t + r16] = acc[s2][t][v];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int idx = lane; idx < 16 * qn; idx += 64) {
+            const int rl = idx / qn, q = idx - rl * qn;
+            if (base + rl < rows) {
+                const float4 v = *reinterpret_cast<const float4 *>(&Cs[rl * LDC + 4 * q]);
+                float *dst = MODE == GEMM_PROJECT ? a.P + (long long)s_slot[base + rl] * a.Dr : a.rec_out + (long long)(row0 + base + rl) * a.De;
+                *reinterpret_cast<float4 *>(dst + 4 * q) = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
