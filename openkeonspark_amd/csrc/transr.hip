@@ -40,7 +40,7 @@ namespace {
 
 struct TrWork {
     float *P = nullptr, *GP = nullptr;
-    int32_t *keys = nullptr, *keys2 = nullptr, *vals = nullptr, *vals2 = nullptr, *job_ent = nullptr;
+    int32_t *keys = nullptr, *keys2 = nullptr, *vals = nullptr, *vals2 = nullptr, *job_ent = nullptr, *row_ent = nullptr;
     int32_t *bucket_start = nullptr;  // [R+2]
     int32_t *tile_rel = nullptr, *tile_row0 = nullptr, *n_tiles = nullptr;
     int32_t *bucket_start4 = nullptr, *tile_row0_4 = nullptr;   // fused tile path: the group-unit maps in ROW units (4 rows per group), for wgrad
@@ -71,6 +71,7 @@ int ensure_work(int64_t slots, int64_t dr, int64_t R) {
         if ((rc = grow(g_w.vals, (size_t)s, "transr vals"))) return rc;
         if ((rc = grow(g_w.vals2, (size_t)s, "transr vals2"))) return rc;
         if ((rc = grow(g_w.job_ent, (size_t)s, "transr job_ent"))) return rc;
+        if ((rc = grow(g_w.row_ent, (size_t)s, "transr row_ent"))) return rc;
         size_t bytes = 0;
         (void)rocprim::radix_sort_pairs(nullptr, bytes, g_w.keys, g_w.keys2, g_w.vals, g_w.vals2, (size_t)s, 0, 32, nullptr);
         if (bytes > g_w.sort_tmp_bytes) {
@@ -311,6 +312,7 @@ struct GemmArgs {
     // fp32 atomics run at ~1.1 TB/s whatever their shape, and 82 MB of them per step were a third of the dgrad kernel
     float *rec_out;
     int32_t *rec_dst;
+    int32_t *row_ent;       // v3: entity of sorted job position p, written by the projection for wgrad3_kernel (one lookup instead of slot -> entity)
 };
 
 template <int MODE>
@@ -888,6 +890,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
 #undef KGE_LOADB3
 #undef KGE_PUTB3
     if (MODE == GEMM_DGRAD && a.rec_out && tid < rows) a.rec_dst[row0 + tid] = s_ent[tid];
+    if (MODE == GEMM_PROJECT && a.row_ent && tid < rows) a.row_ent[row0 + tid] = s_ent[tid];
     if (MODE == GEMM_DGRAD && !a.rec_out) {            // small steps: fp32 atomics straight from the accumulators
 #pragma unroll
         for (int s2 = 0; s2 < RT2; s2++) {
@@ -1095,6 +1098,211 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(GemmArgs a, float *__res
 #undef KGE_WLOAD
 #undef KGE_WFLUSH
 #undef KGE_WPUT
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad v3: g_M[r][i][j] += sum over rows of ent[e_row][i] * GP[slot_row][j] with the products on the bf16 matrix pipe (the
+// three-term split of rows_gemm3_kernel).  The reduction index is the ROW here, so both MFMA operands are transposes of what
+// memory holds (A[i][k = row] = X[row][i], B[k = row][j] = GP[row][j]).  The staged rows go into LDS row-major -- a thread splits one
+// float4 of one row and writes three 8-byte pieces, ten such tasks per thread and 32-row chunk, no transposition in registers -- and
+// the fragments come out with ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 columns and each lane receives one COLUMN's
+// four rows, two such reads are a lane's 8 consecutive k of a 16x16x32 operand.
+// Image: [term][row k (32)][columns], rows of 256 B (the 112-column X half) / 512 B (GP, 208 columns), the 32-byte segment (16
+// columns) of row k rotated by (k & 3) + 4 (k >> 3 & 1): the eight 4 x 16 blocks one transposed read of a 32-lane half touches
+// (rows k .. k + 3 of lane groups 8 rows apart) lie in eight different 32-byte bank groups.
+// Workgroup = the span / half decomposition of wgrad2_kernel.  The ids of a chunk's rows (sorted slot, entity) travel one chunk
+// ahead of its data through a small LDS table, so the data loads issued beside a chunk's matrix work depend on nothing in flight.
+// ---------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int WK3 = 32;
+
+__device__ __forceinline__ int img3_off(int nseg_log2, int term, int k, int c) {      // byte offset of columns c .. c + 3 (c % 4 == 0) of row k
+    const int rot = (k & 3) | (((k >> 3) & 1) << 2);
+    const int seg = ((c >> 4) + rot) & ((1 << nseg_log2) - 1);
+    return ((((term << 5) + k) << nseg_log2) + seg) * 32 + (c & 15) * 2;
+}
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char *img, int nseg_log2, int term, int kbase, int c0, int lane) {
+    // lane 4q + p of a 16-lane group addresses row kbase + q, columns c0 + 4p ..; it receives column c0 + (lane & 15), rows kbase .. + 3
+    const int r16 = lane & 15, q = r16 >> 2, pp = r16 & 3;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4 *)(img + img3_off(nseg_log2, term, kbase + q, c0 + 4 * pp)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4 *)(img + img3_off(nseg_log2, term, kbase + 4 + q, c0 + 4 * pp)));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad3_kernel(GemmArgs a, float *__restrict__ g_mat, int span) {
+    const int n_tiles = a.n_tiles[0];
+    const int t0 = blockIdx.x * span;
+    if (t0 >= n_tiles) return;
+    const int t1 = min(t0 + span, n_tiles);
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[3 * WK3 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char Gs[3 * WK3 * 512];
+    __shared__ int s_ids[2][WK3];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = blockIdx.y;
+    const int i0 = half * LDX2;
+    const int n_it = half == 0 ? WH2 : NT2 - WH2;
+    f32x4 acc[2][NT2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int t2 = 0; t2 < NT2; t2++) acc[s2][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int span_lo = a.tile_row0[t0];
+    const int span_hi = a.tile_row0[t1 - 1] + min(RW2, a.bucket_start[a.tile_rel[t1 - 1] + 1] - a.tile_row0[t1 - 1]);
+    const int qx = (min(a.De, i0 + LDX2) - i0) / 4, qg = a.Dr / 4;   // valid float4 per row
+    // staging tasks: a row of a chunk is 80 float4 -- 28 of the X half, 52 of GP; thread t < 240 owns column quad t % 80 of the rows
+    // t / 80 + 3 u (u = 0 .. 10): its table (X or GP), its column offset and its place in an image row never change
+    constexpr int QROW = LDX2 / 4 + LDB2 / 4;  // 80
+    constexpr int NTASK = (WK3 + 2) / 3;       // 11 row slots per thread (the last one: rows 30, 31)
+    float4 rs[NTASK];
+    const int cq80 = tid % QROW, k0 = tid / QROW;              // k0 = 3: no tasks
+    const bool isx = cq80 < LDX2 / 4;
+    const int cq = isx ? cq80 : cq80 - LDX2 / 4;
+    const bool col_ok = cq < (isx ? qx : qg);
+    const float *tab = isx ? a.ent + i0 + 4 * min(cq, qx - 1) : a.GP + 4 * min(cq, qg - 1);
+    const long long ld = isx ? a.De : a.Dr;
+    unsigned char *img = isx ? Xs : Gs;
+    const int lg = isx ? 3 : 4;
+    // chunk descriptors: the one being multiplied (d0), the one whose data is in flight (d1), the one whose ids are in flight (d2)
+    struct Chunk { int row_first, crow, rel, t, c; bool valid; };
+    auto chunk_at = [&](int t, int c) {
+        Chunk d; d.t = t; d.c = c; d.valid = t < t1;
+        d.rel = 0; d.row_first = 0; d.crow = 1;
+        if (d.valid) {
+            d.rel = a.tile_rel[t];
+            const int row0 = a.tile_row0[t];
+            const int rows_t = min(RW2, a.bucket_start[d.rel + 1] - row0);
+            d.row_first = row0 + c;
+            d.crow = min(WK3, rows_t - c);
+        }
+        return d;
+    };
+    auto chunk_after = [&](const Chunk &d) {
+        if (!d.valid) return d;
+        const int rows_t = min(RW2, a.bucket_start[d.rel + 1] - a.tile_row0[d.t]);
+        int t = d.t, c = d.c + WK3;
+        if (c >= rows_t) { t++; c = 0; }
+        return chunk_at(t, c);
+    };
+    int my_sl = 0, my_e = 0;
+    auto load_ids = [&](const Chunk &d) {           // two independent loads (row_ent: written by the projection kernel)
+        if (tid < WK3 && d.valid) {
+            const int p = d.row_first + min(tid, d.crow - 1);
+            my_sl = a.sorted_slots[p];
+            my_e = a.row_ent[p];
+        }
+    };
+    auto put_ids = [&]() { if (tid < WK3) { s_ids[0][tid] = my_sl; s_ids[1][tid] = my_e; } };
+    auto load_data = [&](const Chunk &d) {
+        if (k0 < 3) {
+            static_for<0, NTASK>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int k = min(k0 + 3 * u, d.crow - 1);
+                const int id = s_ids[isx ? 1 : 0][k];
+                rs[u] = *reinterpret_cast<const float4 *>(tab + (long long)id * ld);
+            });
+        }
+    };
+    auto store_data = [&](const Chunk &d) {
+        if (k0 < 3) {
+            static_for<0, NTASK>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int k = k0 + 3 * u;
+                if (u < NTASK - 1 || k < WK3) {
+                    const float4 v = keep_if(k < d.crow && col_ok, rs[u]);
+                    uint2 p1, p2, p3;
+                    split3_pair(v.x, v.y, p1.x, p2.x, p3.x);
+                    split3_pair(v.z, v.w, p1.y, p2.y, p3.y);
+                    *reinterpret_cast<uint2 *>(img + img3_off(lg, 0, k, 4 * cq)) = p1;
+                    *reinterpret_cast<uint2 *>(img + img3_off(lg, 1, k, 4 * cq)) = p2;
+                    *reinterpret_cast<uint2 *>(img + img3_off(lg, 2, k, 4 * cq)) = p3;
+                }
+            });
+        }
+    };
+#define KGE_W3PUT(i_, j_, v_)                                                                                 \
+    if ((i_) < a.De && (j_) < a.Dr && (v_) != 0.f) {                                                          \
+        if (sole) G[(long long)(i_) * a.Dr + (j_)] = (v_);                                                    \
+        else __builtin_amdgcn_global_atomic_fadd_f32(                                                         \
+                (__attribute__((address_space(1))) float *)(G + (long long)(i_) * a.Dr + (j_)), (v_));        \
+    }
+#define KGE_W3FLUSH(rel_)                                                                                     \
+    {                                                                                                         \
+        float *G = g_mat + (long long)(rel_) * a.De * a.Dr;                                                   \
+        const bool sole = a.bucket_start[rel_] >= span_lo && a.bucket_start[(rel_) + 1] <= span_hi;           \
+        _Pragma("unroll") for (int s2 = 0; s2 < 2; s2++) {                                                    \
+            _Pragma("unroll") for (int t2 = 0; t2 < NT2; t2++) {                                              \
+                const int j = t2 * 16 + (lane & 15);                                                          \
+                if (wave + 4 * s2 < n_it) {                                                                   \
+                    _Pragma("unroll") for (int v = 0; v < 4; v++) {                                           \
+                        const int i = i0 + (wave + 4 * s2) * 16 + 4 * (lane >> 4) + v;                        \
+                        KGE_W3PUT(i, j, acc[s2][t2][v])                                                       \
+                    }                                                                                         \
+                }                                                                                             \
+                acc[s2][t2] = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+    Chunk d0 = chunk_at(t0, 0), d1 = chunk_after(d0), d2 = chunk_after(d1);
+    int r_cur = d0.rel;
+    load_ids(d0);
+    put_ids();
+    __syncthreads();
+    load_data(d0);
+    load_ids(d1);
+    bool first = true;
+    const int G4 = lane >> 4;
+    while (true) {
+        if (!first) __syncthreads();          // the previous chunk's fragment reads (and its readers of s_ids) are done
+        first = false;
+        store_data(d0);
+        put_ids();                            // the ids of d1's rows (loaded a chunk ago)
+        if (d0.rel != r_cur) {                // (here, between the staging stores and the next loads, no staged row is live in registers)
+            KGE_W3FLUSH(r_cur)
+            r_cur = d0.rel;
+        }
+        __syncthreads();
+        if (d1.valid) load_data(d1);          // in flight during the matrix work
+        load_ids(d2);
+        {
+            bf16x8 af[2][3];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                for (int t = 0; t < 3; t++) af[s2][t] = tr_frag(Xs, 3, t, 8 * G4, min(wave + 4 * s2, WH2 - 1) * 16, lane);
+            bf16x8 bf[2][3];
+            auto fetch = [&](int buf, int jt) {
+#pragma unroll
+                for (int t = 0; t < 3; t++) bf[buf][t] = tr_frag(Gs, 4, t, 8 * G4, jt * 16, lane);
+            };
+            fetch(0, 0);
+            static_for<0, NT2>([&](auto tc) {
+                constexpr int jt = decltype(tc)::value;
+                constexpr int cur = jt & 1;
+                if constexpr (jt + 1 < NT2) fetch(cur ^ 1, jt + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    f32x4 c = acc[s2][jt];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][0], bf[cur][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][2], bf[cur][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][1], bf[cur][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][0], bf[cur][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][1], bf[cur][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][0], bf[cur][0], c, 0, 0, 0);
+                    acc[s2][jt] = c;
+                }
+            });
+        }
+        if (!d1.valid) break;
+        d0 = d1; d1 = d2; d2 = chunk_after(d2);
+    }
+    KGE_W3FLUSH(r_cur)
+#undef KGE_W3FLUSH
+#undef KGE_W3PUT
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1534,7 +1742,7 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     ga.sorted_slots = g_w.vals2; ga.job_ent = g_w.job_ent; ga.bucket_start = g_w.bucket_start;
     ga.tile_rel = g_w.tile_rel; ga.tile_row0 = g_w.tile_row0; ga.n_tiles = g_w.n_tiles;
     ga.De = De; ga.Dr = Dr;
-    ga.rec_out = drec; ga.rec_dst = ddst;
+    ga.rec_out = drec; ga.rec_dst = ddst; ga.row_ent = g_w.row_ent;
     const unsigned max_tiles = (unsigned)(slots / (v2 ? RW2 : 32) + R + 1);
     // sparse buckets (config #4's auto batch: 46 rows per relation, ~one tile per relation, fewer tiles than CUs): two column
     // blocks of 7 tiles per row tile instead of one of 13
@@ -1572,7 +1780,8 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
             // single owner): one tile per workgroup so that every tile is in flight
             const int span = (slots >= 256 * R || opt == 2) ? SPAN2 : 1;
             const dim3 wg2((max_tiles + span - 1) / span, 2);
-            hipLaunchKernelGGL(wgrad2_kernel, wg2, dim3(256), 0, stream, ga, grads[2], span);
+            if (v3) hipLaunchKernelGGL(wgrad3_kernel, wg2, dim3(256), 0, stream, ga, grads[2], span);
+            else hipLaunchKernelGGL(wgrad2_kernel, wg2, dim3(256), 0, stream, ga, grads[2], span);
         } else {
             const int tiles_i1 = (De + 31) / 32;
             const int wgt = WG_TILES * 32 / RW2;   // the same 256 rows between flushes as with 32-row tiles
