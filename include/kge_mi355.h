@@ -263,6 +263,19 @@ int kge_stream_wait_emit(void *stream);
 int kge_forward_backward_sgd_rows(const kge_model_desc *m, float *const tables[KGE_MAX_TABLES], const int32_t *d_h, const int32_t *d_t,
                                   const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom, float lr, float *d_loss, void *stream);
 int kge_sgd_rows_skipped(int32_t *n_negatives);
+/* The same update across N ranks (replaces the per-variable scatter_sub the reference's workers send to the parameter servers,
+ * distribute_training.py:99-101,193-196): kge_forward_backward_records stores the gradient rows of THIS rank's slice of the batch
+ * as float records (d_rec [*, dim], destination keys d_dst) into its slice [rec_offset, rec_offset + rec_slice) of two buffers the
+ * caller owns (unused positions of the slice get key -1), the caller all-gathers the slices, and kge_float_records_apply sums ALL
+ * n_records records by destination row and adds -lr * sum to the rows of every replica -- the sparse touched-row exchange; the
+ * replicas stay identical because every rank reduces the same records in the same order.  n_pos_total = positives of the GLOBAL
+ * batch (it fixes the virtual row space of the keys, which must be the same on all ranks); `denom` the global denominator;
+ * d_loss receives this rank's share of the loss.  kge_sgd_rows_skipped applies as above. */
+int kge_forward_backward_records(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES], const int32_t *d_h, const int32_t *d_t,
+                                 const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom, INT n_pos_total, float *d_rec,
+                                 int32_t *d_dst, INT rec_offset, INT rec_slice, float *d_loss, void *stream);
+int kge_float_records_apply(const kge_model_desc *m, float *const tables[KGE_MAX_TABLES], const float *d_rec, int32_t *d_dst, INT n_records,
+                            INT n_pos_total, INT n_neg, float lr, void *stream);
 /* 1 when kge_forward_backward on a step of this shape takes the TransH / TransD pair-count path (whose emit kernel also records
  * the event above), else 0 */
 int kge_pair_path_active(const kge_model_desc *m, INT n_pos, INT n_neg);

@@ -361,8 +361,8 @@ class Config(object):
         self._first_pos = first.value
         if self._dp and self.trainModel is not None and getattr(self, "_dist_ready", 0) != self.world_size:
             if getattr(self, "sparse_inplace", False):
-                raise KgeError("row-wise SGD in place (sparse_rows with TransH / TransD) is single-process")
-            if self.sparse_rows:
+                pass          # replicated tables, the step's gradient records all-gathered (_records_step): nothing to lay out
+            elif self.sparse_rows:
                 self._setup_shards()
             else:
                 self._setup_flat_buffers()
@@ -782,7 +782,11 @@ class Config(object):
         # small steps are launch-bound: the single fused atomic kernel beats the multi-stage count pipeline
         # (same decision on every rank: it depends on the global batch only)
         big = (self.batch_size if batch_h is None else n_pos) * (3 + n_neg) >= self.counts_min_records * self.world_size
-        if self.sparse_inplace:
+        if self.sparse_inplace and self._dp:
+            self._records_step(dev, n_pos, stride, denom)
+            if batch_h is None and self.prefetch_sampling:
+                self._prefetch_next_batch()
+        elif self.sparse_inplace:
             _lib.check(self.lib.kge_forward_backward_sgd_rows(
                 ctypes.byref(self._desc), self._tab_ptrs, dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), n_pos, n_neg,
                 stride, denom, float(self.alpha), self._loss.data_ptr(), self._stream()), self.lib)
@@ -920,6 +924,39 @@ class Config(object):
         self._loss.copy_(losses[-1:])
         self.trainModel.loss = self._loss
         return out
+
+    def _records_step(self, dev_batch, n_pos, stride, denom):
+        """Row-wise SGD in place across ranks (TransH / TransD, or TransE off the sign-count path, with sparse_rows): the tables
+        are replicated; every rank turns ITS slice of the batch into float gradient records, the records (rows + destination
+        keys) are all-gathered -- the sparse touched-row exchange: only rows a step touches travel -- and every rank adds -lr * the
+        per-row sums of ALL records to its replica.  Every rank reduces the same records in the same order, so the replicas stay
+        bit-identical; against the single-process step the per-row sums differ in fp32 order only.  Replaces the scatter_sub
+        updates the reference's workers send to its parameter servers (distribute_training.py:99-101,193-196)."""
+        import torch
+        from .parallel import all_gather_chunks, allreduce_sum, max_slice_positions
+        n_neg = self.negative_ent + self.negative_rel
+        W, D = self.world_size, self.hidden_size
+        slots = {_lib.TRANSE: 3 + n_neg, _lib.TRANSH: 4 + n_neg, _lib.TRANSD: 6 + 2 * n_neg}[self.trainModel.model_id]
+        b = getattr(self, "_rec_buf", None)
+        if b is None or b["slots"] != slots:
+            per = max_slice_positions(self.lib, self.batch_size, W, self.workThreads) * slots     # records per rank's slice
+            b = dict(slots=slots, per=per,
+                     rec=torch.zeros((W * per, D), dtype=torch.float32, device=self.device),
+                     dst=torch.full((W * per,), -1, dtype=torch.int32, device=self.device))
+            self._rec_buf = b
+        per, off = b["per"], self.rank * b["per"]
+        _lib.check(self.lib.kge_forward_backward_records(
+            ctypes.byref(self._desc), self._tab_ptrs, dev_batch[0].data_ptr(), dev_batch[1].data_ptr(), dev_batch[2].data_ptr(),
+            n_pos, n_neg, stride, denom, self.batch_size, b["rec"].data_ptr(), b["dst"].data_ptr(), off, per,
+            self._loss.data_ptr(), self._stream()), self.lib)
+        if W > 1:
+            all_gather_chunks(b["rec"].view(-1), b["rec"][off:off + per].view(-1), self._pg)
+            all_gather_chunks(b["dst"], b["dst"][off:off + per], self._pg)
+            allreduce_sum([self._loss], self._pg)
+        _lib.check(self.lib.kge_float_records_apply(
+            ctypes.byref(self._desc), self._tab_ptrs, b["rec"].data_ptr(), b["dst"].data_ptr(), W * per, self.batch_size, n_neg,
+            float(self.alpha), self._stream()), self.lib)
+        self.global_step += 1
 
     def _sparse_step(self, dev_batch, n_pos, stride, denom, check_shape=False):
         """Sparse-row TransE step on ONE GPU: emit int8 records -> sort by destination row -> compact per-row counts ->

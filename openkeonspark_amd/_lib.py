@@ -77,6 +77,8 @@ def _declare(L):
     L.kge_pair_path_active.argtypes = [ctypes.POINTER(ModelDesc), i64, i64]
     L.kge_loss_limbs_target.argtypes = [vp]
     L.kge_forward_backward_sgd_rows.argtypes = [ctypes.POINTER(ModelDesc), tabs, vp, vp, vp, i64, i64, i64, i64, f32, vp, vp]
+    L.kge_forward_backward_records.argtypes = [ctypes.POINTER(ModelDesc), tabs, vp, vp, vp, i64, i64, i64, i64, i64, vp, vp, i64, i64, vp, vp]
+    L.kge_float_records_apply.argtypes = [ctypes.POINTER(ModelDesc), tabs, vp, vp, i64, i64, i64, f32, vp]
     L.kge_forward_backward_sampled.argtypes = [ctypes.POINTER(ModelDesc), tabs, vp, vp, vp, i64, i64, i64, i64, tabs, vp, vp]
     L.kge_loss_to_limbs.argtypes = [vp, vp, vp]
     L.kge_limbs_to_loss.argtypes = [vp, vp, vp]

@@ -393,6 +393,20 @@ int kge_forward_backward_sgd_rows(const kge_model_desc *m, float *const tables[K
     return launch_forward_backward(*m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, tables, d_loss, (hipStream_t)stream, false, lr);
 }
 
+int kge_forward_backward_records(const kge_model_desc *m, const float *const tables[KGE_MAX_TABLES], const int32_t *d_h, const int32_t *d_t,
+                                 const int32_t *d_r, INT n_pos, INT n_neg, INT stride, INT denom, INT n_pos_total, float *d_rec,
+                                 int32_t *d_dst, INT rec_offset, INT rec_slice, float *d_loss, void *stream) {
+    if (!m || !tables || !d_loss) return fail(KGE_ERR_BAD_ARG, "kge_forward_backward_records: null argument");
+    return launch_forward_backward_records(*m, tables, d_h, d_t, d_r, n_pos, n_neg, stride, denom, n_pos_total, d_rec, d_dst, rec_offset,
+                                           rec_slice, d_loss, (hipStream_t)stream);
+}
+
+int kge_float_records_apply(const kge_model_desc *m, float *const tables[KGE_MAX_TABLES], const float *d_rec, int32_t *d_dst, INT n_records,
+                            INT n_pos_total, INT n_neg, float lr, void *stream) {
+    if (!m || !tables) return fail(KGE_ERR_BAD_ARG, "kge_float_records_apply: null argument");
+    return launch_float_records_apply(*m, tables, d_rec, d_dst, n_records, n_pos_total, n_neg, lr, (hipStream_t)stream);
+}
+
 int kge_loss_limbs_target(int32_t *d_limbs4) {
     engine().loss_limbs = d_limbs4;
     return KGE_OK;

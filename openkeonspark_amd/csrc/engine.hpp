@@ -145,7 +145,15 @@ struct FloatRowSpace {   // virtual row space of models.hip's FbArgs::frec recor
 bool pair_path_active(const kge_model_desc &m, int64_t n_pos, int64_t n_neg);
 int sgd_rows_skipped(int32_t *out);
 int float_records_workspace(int64_t M, int D, float *&rec, int32_t *&dst);
-int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t stream);
+// rec_ext / dst_ext: records held by the caller (the gathered records of a data-parallel step) instead of the workspace's
+// deterministic: stable sort + one team per run + ordered fold of the hub copies (bit-identical on every rank that reduces the same records)
+int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t stream, const float *rec_ext = nullptr, int32_t *dst_ext = nullptr,
+                         bool deterministic = false);
+int launch_forward_backward_records(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
+                                    const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride, int64_t denom, int64_t n_pos_total,
+                                    float *d_rec, int32_t *d_dst, int64_t rec_offset, int64_t rec_slice, float *d_loss, hipStream_t stream);
+int launch_float_records_apply(const kge_model_desc &m, float *const tables[4], const float *d_rec, int32_t *d_dst, int64_t M_total,
+                               int64_t n_pos_total, int64_t n_neg, float lr, hipStream_t stream);
 
 // device-side index build (index_build.hip)
 bool device_index_build_supported(int64_t E, int64_t R, int64_t n);

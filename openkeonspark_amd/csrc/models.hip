@@ -1072,6 +1072,88 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
                                    const int32_t *d_t, const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride,
                                    int64_t denom, float *const grads[4], float *d_loss, hipStream_t stream, bool sampler_shaped);
 
+// virtual row space of a step's float gradient records: entity rows, then hub_k copies of the relation-side rows
+struct RecordSpace { int64_t slots, ent_rows, hub_rows, hub_k, rows; };
+static RecordSpace record_space(const kge_model_desc &m, int64_t n_pos, int64_t n_neg) {
+    RecordSpace s;
+    s.slots = m.model == KGE_TRANSE ? 3 + n_neg : (m.model == KGE_TRANSH ? 4 + n_neg : 6 + 2 * n_neg);
+    // relation-side rows are hubs: every group writes 1 (TransE) or 2 of them, onto only R or 2R rows.  Group b writes
+    // into virtual copy b mod hub_k, with hub_k chosen so that a copy of a row still collects ~64 records: the sort
+    // buckets stay bounded AND the segmented sum folds a run of ~64 records into ONE atomic row add (one copy per
+    // record would put every record's 4*D bytes through same-address atomics again: measured 82 us for 43 k records).
+    s.ent_rows = (m.model == KGE_TRANSD ? 2 : 1) * m.ent_total;
+    s.hub_rows = (m.model == KGE_TRANSE ? 1 : 2) * m.rel_total;
+    const int64_t group_rel = m.model == KGE_TRANSE ? 1 : 2;
+    s.hub_k = s.hub_rows > 0 ? (group_rel * n_pos) / (s.hub_rows * 64) : 1;
+    if (s.hub_k < 1) s.hub_k = 1;
+    if (s.hub_k > 4096) s.hub_k = 4096;
+    s.rows = s.ent_rows + s.hub_k * s.hub_rows;
+    return s;
+}
+
+// Data-parallel form of the row-wise SGD in place (kge_forward_backward_sgd_rows cut in two): every rank stores the gradient rows
+// of ITS slice of the batch as float records into its slice [rec_offset, rec_offset + rec_slice) of a buffer all ranks then
+// all-gather, and every rank applies ALL records to its replica (launch_float_records_apply) -- the touched-row exchange of
+// north_star; the replicas stay identical because every rank sums the same records in the same order.  The row space (hub copies)
+// is that of the GLOBAL batch, so all ranks key their records alike.
+int launch_forward_backward_records(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
+                                    const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride, int64_t denom, int64_t n_pos_total,
+                                    float *d_rec, int32_t *d_dst, int64_t rec_offset, int64_t rec_slice, float *d_loss, hipStream_t stream) {
+    Engine &e = engine();
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_forward_backward_records: no usable HIP device");
+    if (n_pos < 0 || n_neg < 1 || stride < n_pos || denom <= 0 || n_pos_total < n_pos || !d_rec || !d_dst || rec_offset < 0)
+        return fail(KGE_ERR_BAD_ARG, "kge_forward_backward_records: bad arguments");
+    if (m.model != KGE_TRANSE && m.model != KGE_TRANSH && m.model != KGE_TRANSD)
+        return fail(KGE_ERR_UNSUPPORTED, "gradient rows as float records: TransE / TransH / TransD only");
+    if (m.ent_dim != m.rel_dim) return fail(KGE_ERR_BAD_ARG, "TransE/H/D need ent_dim == rel_dim (hidden_size)");
+    int rc;
+    if ((rc = ensure_loss_buffers())) return rc;
+    const RecordSpace sp = record_space(m, n_pos_total, n_neg);
+    const int64_t M = n_pos * sp.slots;
+    if (M > rec_slice) return fail(KGE_ERR_BAD_ARG, "kge_forward_backward_records: the slice is smaller than this rank's records");
+    if (sp.rows >= (int64_t(1) << 31) - 1 || m.ent_dim > 1024) return fail(KGE_ERR_UNSUPPORTED, "gradient rows as float records: row space too large");
+    // the part of the slice this rank does not fill carries no record
+    if (rec_slice > M && (rc = hip_check(hipMemsetAsync(d_dst + rec_offset + M, 0xff, sizeof(int32_t) * (size_t)(rec_slice - M), stream), "blank record keys"))) return rc;
+    if (n_pos == 0) return hip_check(hipMemsetAsync(d_loss, 0, sizeof(float), stream), "zero loss");
+    FbArgs a = {};
+    a.ent = tables[0]; a.rel = tables[1]; a.auxr = tables[2]; a.auxe = tables[3];
+    a.bh = d_h; a.bt = d_t; a.br = d_r;
+    a.n_pos = n_pos; a.n_neg = n_neg; a.stride = stride;
+    a.D = m.ent_dim; a.margin = m.margin; a.unit = 1.0f / (float)denom;
+    a.loss_partials = e.dev.loss_partials;
+    a.negative_rel = m.negative_rel;
+    a.frec = d_rec + (size_t)rec_offset * a.D; a.fdst = d_dst + rec_offset;
+    a.ent_total = (int)m.ent_total; a.rel_total = (int)m.rel_total;
+    a.hub_base = sp.ent_rows; a.hub_k = (int)sp.hub_k; a.hub_rows = (int)sp.hub_rows;
+    if (!g_skipped && (rc = hip_check(hipMalloc(&g_skipped, sizeof(int32_t)), "alloc skipped-negatives counter"))) return rc;
+    if ((rc = hip_check(hipMemsetAsync(g_skipped, 0, sizeof(int32_t), stream), "zero skipped-negatives counter"))) return rc;
+    a.skipped = g_skipped;
+    switch (m.model) {
+        case KGE_TRANSE: rc = dispatch_fb_records<KGE_TRANSE>(a, d_loss, stream); break;
+        case KGE_TRANSH: rc = dispatch_fb_records<KGE_TRANSH>(a, d_loss, stream); break;
+        default: rc = dispatch_fb_records<KGE_TRANSD>(a, d_loss, stream); break;
+    }
+    if (rc) return rc;
+    return hip_check(hipGetLastError(), "forward_backward records launch");
+}
+
+int launch_float_records_apply(const kge_model_desc &m, float *const tables[4], const float *d_rec, int32_t *d_dst, int64_t M_total,
+                               int64_t n_pos_total, int64_t n_neg, float lr, hipStream_t stream) {
+    if (!device_ok()) return fail(KGE_ERR_NO_DEVICE, "kge_float_records_apply: no usable HIP device");
+    if (!d_rec || !d_dst || M_total < 0 || n_pos_total < 0 || !(lr > 0.f)) return fail(KGE_ERR_BAD_ARG, "kge_float_records_apply: bad arguments");
+    if (m.model != KGE_TRANSE && m.model != KGE_TRANSH && m.model != KGE_TRANSD)
+        return fail(KGE_ERR_UNSUPPORTED, "gradient rows as float records: TransE / TransH / TransD only");
+    if (M_total == 0) return KGE_OK;
+    if (M_total >= (int64_t(1) << 31)) return fail(KGE_ERR_UNSUPPORTED, "kge_float_records_apply: too many records for the record sort");
+    const RecordSpace sp = record_space(m, n_pos_total, n_neg);
+    FloatRowSpace rs;
+    rs.g_ent = tables[0]; rs.g_rel = tables[1]; rs.g_auxr = tables[2]; rs.g_auxe = tables[3];
+    rs.E = m.ent_total; rs.R = m.rel_total; rs.hub_base = sp.ent_rows; rs.hub_rows = sp.hub_rows; rs.rows = sp.rows;
+    rs.scale = -lr;
+    tables_written();
+    return float_records_reduce(M_total, m.ent_dim, rs, stream, d_rec, d_dst, true);
+}
+
 int launch_forward_backward(const kge_model_desc &m, const float *const tables[4], const int32_t *d_h, const int32_t *d_t,
                             const int32_t *d_r, int64_t n_pos, int64_t n_neg, int64_t stride, int64_t denom,
                             float *const grads[4], float *d_loss, hipStream_t stream, bool sampler_shaped, float inplace_lr) {
@@ -1142,19 +1224,9 @@ int launch_forward_backward(const kge_model_desc &m, const float *const tables[4
     // Float-record path: gradient rows are stored as records, ordered by destination row and summed by
     // segments into the accumulators (plain stores + one sorted pass instead of memory-side fp32 atomics,
     // which cap at ~1.1 TB/s).  Worth it once a step has enough rows to fill the chip.
-    const int64_t slots = m.model == KGE_TRANSE ? 3 + n_neg : (m.model == KGE_TRANSH ? 4 + n_neg : 6 + 2 * n_neg);
+    const RecordSpace sp = record_space(m, n_pos, n_neg);
+    const int64_t slots = sp.slots, ent_rows = sp.ent_rows, hub_rows = sp.hub_rows, hub_k = sp.hub_k, rows = sp.rows;
     const int64_t M = n_pos * slots;
-    // relation-side rows are hubs: every group writes 1 (TransE) or 2 of them, onto only R or 2R rows.  Group b writes
-    // into virtual copy b mod hub_k, with hub_k chosen so that a copy of a row still collects ~64 records: the sort
-    // buckets stay bounded AND the segmented sum folds a run of ~64 records into ONE atomic row add (one copy per
-    // record would put every record's 4*D bytes through same-address atomics again: measured 82 us for 43 k records).
-    const int64_t ent_rows = (m.model == KGE_TRANSD ? 2 : 1) * m.ent_total;
-    const int64_t hub_rows = (m.model == KGE_TRANSE ? 1 : 2) * m.rel_total;
-    const int64_t group_rel = m.model == KGE_TRANSE ? 1 : 2;
-    int64_t hub_k = hub_rows > 0 ? (group_rel * n_pos) / (hub_rows * 64) : 1;
-    if (hub_k < 1) hub_k = 1;
-    if (hub_k > 4096) hub_k = 4096;
-    const int64_t rows = ent_rows + hub_k * hub_rows;
     const bool records_fit = M < (int64_t(1) << 31) && rows < (int64_t(1) << 31) - 1 && a.D <= 1024;
     if (inplace_lr != 0.f && !records_fit) return fail(KGE_ERR_UNSUPPORTED, "row-wise SGD in place: step or row space too large for the record sort");
     if (n_pos == 0 && inplace_lr != 0.f) return hip_check(hipMemsetAsync(d_loss, 0, sizeof(float), stream), "zero loss");

@@ -42,6 +42,8 @@ int bits_for_rows(int64_t v) { int b = 1; while ((int64_t(1) << b) <= v) b++; re
 
 struct CtWork {
     uint32_t *rec = nullptr;
+    float *hub_sums = nullptr;         // deterministic float-record reduce: per-copy sums of the relation-side rows
+    size_t hub_sums_cap = 0;
     int32_t *dst = nullptr, *dst_sorted = nullptr, *ids = nullptr, *ids_sorted = nullptr;
     int32_t *n_valid = nullptr;
     int32_t *tile_hist = nullptr, *bucket_start = nullptr;   // LDS-bucket path: bucket totals + cursors, bucket starts
@@ -716,6 +718,61 @@ __global__ __launch_bounds__(256) void segsum_f32_kernel(const float *__restrict
 }
 
 
+// Deterministic form of the float-record sum, for the data-parallel row-wise SGD (every rank reduces the same gathered records and
+// the replicas must come out bit-identical): the records are ordered by a STABLE sort (rocPRIM radix sort: equal keys keep their
+// record order), ONE team sums a whole run of equal keys in that order, an entity-side row has a single run and is updated by its
+// team alone, and the hub copies of a relation-side row are first summed per copy into hub_sums [copy][hub row][D] and then folded in
+// copy order by one thread per element (hub_fold_det_kernel).  No atomics, no order that depends on scheduling.
+template <int L, int C>
+__global__ __launch_bounds__(256) void segsum_f32_runs_kernel(const float *__restrict__ rec, const int32_t *__restrict__ keys,
+                                                              const int32_t *__restrict__ ids, const int32_t *__restrict__ n_valid_p,
+                                                              FloatRowSpace rs, int D, float *__restrict__ hub_sums) {
+    constexpr int TEAMS = 256 / L;
+    const int lane = threadIdx.x % L;
+    const int n_valid = n_valid_p[0];
+    for (long long i = (long long)blockIdx.x * TEAMS + threadIdx.x / L; i < n_valid; i += (long long)gridDim.x * TEAMS) {
+        const int key = keys[i];
+        if (i > 0 && keys[i - 1] == key) continue;           // not the first record of its run
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) acc[c] = 0.f;
+        long long j = i;
+        do {
+            const float *p = rec + (long long)ids[j] * D;
+#pragma unroll
+            for (int c = 0; c < C; c++) { const int e = lane + L * c; if (e < D) acc[c] += p[e]; }
+            j++;
+        } while (j < n_valid && keys[j] == key);
+        if (key < rs.hub_base) {
+            float *p = float_row_ptr(rs, key, D);
+#pragma unroll
+            for (int c = 0; c < C; c++) { const int e = lane + L * c; if (e < D) p[e] += mul_rn(rs.scale, acc[c]); }
+        } else {
+            float *p = hub_sums + (long long)(key - rs.hub_base) * D;
+#pragma unroll
+            for (int c = 0; c < C; c++) { const int e = lane + L * c; if (e < D) p[e] = acc[c]; }
+        }
+    }
+}
+
+// relation-side rows: the copies' sums in copy order (and the buffer re-zeroed for the next step)
+__global__ __launch_bounds__(256) void hub_fold_det_kernel(float *__restrict__ hub_sums, FloatRowSpace rs, int D, int K) {
+    const long long n = rs.hub_rows * D;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        bool any = false;
+        for (int k = 0; k < K; k++) {
+            const float v = hub_sums[(long long)k * n + i];
+            if (v != 0.f) { s += v; any = true; hub_sums[(long long)k * n + i] = 0.f; }
+        }
+        if (any) {
+            const long long q = i / D, e = i - q * D;
+            float *p = q < rs.R ? rs.g_rel + q * D : rs.g_auxr + (q - rs.R) * D;
+            p[e] += mul_rn(rs.scale, s);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pair-count path (TransH / TransD; stage 1 is pairs.hip's pair_emit_kernel): int8 sign records keyed by
 // (entity x, relation r) as x*R + r.  The records of a key are summed as integers; at the end of a run the
@@ -913,12 +970,24 @@ int float_records_workspace(int64_t M, int D, float *&rec, int32_t *&dst) {
     return KGE_OK;
 }
 
-int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t stream) {
+int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t stream, const float *rec_ext, int32_t *dst_ext, bool deterministic) {
     int rc;
+    // records held by the caller: size the sort's work buffers for M, then let the launches below read the caller's arrays (the
+    // pointers are passed by value at launch, so the workspace's own are put back before returning)
+    struct Swap {
+        uint32_t *rec; int32_t *dst; bool on;
+        ~Swap() { if (on) { g_c.rec = rec; g_c.dst = dst; } }
+    } swap = {g_c.rec, g_c.dst, false};
+    if (rec_ext && dst_ext) {
+        if ((rc = ensure_counts_work(M, (size_t)D))) return rc;
+        swap.rec = g_c.rec; swap.dst = g_c.dst; swap.on = true;
+        g_c.rec = reinterpret_cast<uint32_t *>(const_cast<float *>(rec_ext));
+        g_c.dst = dst_ext;
+    }
     const int rows = (int)rs.rows;
     const int32_t *n_valid_p = nullptr;
     const int rpb = (rows + NB - 1) / NB;
-    if (rpb <= 8192 && !engine().counts_force_sort) {
+    if (rpb <= 8192 && !engine().counts_force_sort && !deterministic) {
         const int n_tiles = (int)((M + BTILE - 1) / BTILE);
         if (!g_c.bucket_start) {
             if ((rc = regrow(g_c.bucket_start, NB + 2, "counts bucket_start"))) return rc;
@@ -943,6 +1012,32 @@ int float_records_reduce(int64_t M, int D, const FloatRowSpace &rs, hipStream_t 
         n_valid_p = g_c.n_valid;
     }
     const float *rec = reinterpret_cast<const float *>(g_c.rec);
+    if (deterministic) {
+        const int64_t hub_virtual = rs.rows - rs.hub_base;          // copies x hub rows
+        const int K = rs.hub_rows > 0 ? (int)(hub_virtual / rs.hub_rows) : 0;
+        const size_t need = (size_t)hub_virtual * D;
+        if (need > g_c.hub_sums_cap) {
+            if ((rc = regrow(g_c.hub_sums, need, "hub copy sums"))) return rc;
+            if ((rc = hip_check(hipMemsetAsync(g_c.hub_sums, 0, sizeof(float) * need, stream), "zero hub copy sums"))) return rc;
+            g_c.hub_sums_cap = need;
+        }
+#define KGE_SEGR(LL, CC)                                                                                              \
+    {                                                                                                                 \
+        long long nb = (M + (256 / LL) - 1) / (256 / LL);                                                             \
+        if (nb > 16384) nb = 16384;                                                                                   \
+        hipLaunchKernelGGL((segsum_f32_runs_kernel<LL, CC>), dim3((unsigned)nb), dim3(256), 0, stream, rec, g_c.dst_sorted, \
+                           g_c.ids_sorted, n_valid_p, rs, D, g_c.hub_sums);                                           \
+    }
+        if (D <= 16) KGE_SEGR(16, 1) else if (D <= 32) KGE_SEGR(16, 2) else if (D <= 64) KGE_SEGR(16, 4)
+        else if (D <= 128) KGE_SEGR(32, 4) else if (D <= 256) KGE_SEGR(64, 4) else if (D <= 512) KGE_SEGR(64, 8) else KGE_SEGR(64, 16)
+#undef KGE_SEGR
+        if (K > 0) {
+            long long nb = (rs.hub_rows * D + 255) / 256;
+            if (nb > 4096) nb = 4096;
+            hipLaunchKernelGGL(hub_fold_det_kernel, dim3((unsigned)nb), dim3(256), 0, stream, g_c.hub_sums, rs, D, K);
+        }
+        return hip_check(hipGetLastError(), "float records deterministic reduce launch");
+    }
     // shorter chunks while the step is small: the per-team record loop is a chain of dependent loads
     const int chunk_len = M >= (int64_t(1) << 20) ? 64 : (M >= (int64_t(1) << 18) ? 32 : 16);
 #define KGE_SEGF(LL, CC)                                                                                              \
