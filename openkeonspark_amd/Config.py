@@ -248,6 +248,7 @@ class Config(object):
         '''
         import torch
         self.model = model
+        self._shard_plan = self._plan_entity_shard(model)
         self.trainModel = self.model(config=self, define=True)
         m = self.trainModel
         self._desc = m.descriptor()
@@ -266,20 +267,8 @@ class Config(object):
         # [touched rows, D] image and only those rows are updated; across ranks the records themselves are
         # all-gathered (the sparse touched-row exchange of BASELINE config #5).  SGD only: TF1's sparse Adam
         # sweeps every row of m, v and the table each step, which is the dense path by definition.
-        table_bytes = (self.entTotal + self.relTotal) * self.hidden_size * 4
         requested = getattr(self, "sparse_rows", None)   # None = automatic, True / False = the caller's wish
-        sparse = requested
-        if sparse is None:
-            # Measured cross-over on one MI355X (tools/sparse_crossover.sh, profiles/r03_sparse_crossover.jsonl: dim 512,
-            # B = 131 072, n = 1, tables of 0.26 .. 8.2 GB): the dense step costs the batch's work plus a sweep of the whole
-            # table and count image, the sparse step the batch's work plus its sort -- they tie at 0.26 GB (0.68 vs 0.70 ms),
-            # sparse rows win by 18 % at 0.5 GB and 5.4x at 8 GB.  The tie sits where the table is ~0.3x the bytes of the rows
-            # a step touches (1.07 GB there); below 128 MB the dense path's image fits the caches and it is kept.
-            touched_bytes = self.batch_size * (3 + n_neg) * self.hidden_size * 4
-            threshold = getattr(self, "sparse_threshold_bytes", None)
-            if threshold is None:
-                threshold = max(128 << 20, int(0.3 * touched_bytes))
-            sparse = table_bytes > int(threshold)
+        table_bytes, sparse = self._wants_sparse_rows(n_neg)
         self.sparse_rows = (bool(sparse) or self._lazy_adam) and self.use_counts and not self._adam
         # TransH / TransD (and TransE outside the sign-count path) with SGD: the touched rows are updated in place from float
         # gradient records (kge_forward_backward_sgd_rows) -- no gradient tables, no sweep.  On request, or by itself for tables
@@ -322,6 +311,51 @@ class Config(object):
             self._counts = torch.zeros((self.entTotal + self.relTotal, self.hidden_size), dtype=torch.int32,
                                        device=self.device)
         self._setup_partition()
+
+    def _wants_sparse_rows(self, n_neg):
+        """(table bytes, sparse rows wanted?) -- the caller's wish (`sparse_rows` True / False) or, left at None, the measured rule."""
+        table_bytes = (self.entTotal + self.relTotal) * self.hidden_size * 4
+        sparse = getattr(self, "sparse_rows", None)
+        if sparse is None:
+            # Measured cross-over on one MI355X (tools/sparse_crossover.sh, profiles/r03_sparse_crossover.jsonl: dim 512,
+            # B = 131 072, n = 1, tables of 0.26 .. 8.2 GB): the dense step costs the batch's work plus a sweep of the whole
+            # table and count image, the sparse step the batch's work plus its sort -- they tie at 0.26 GB (0.68 vs 0.70 ms),
+            # sparse rows win by 18 % at 0.5 GB and 5.4x at 8 GB.  The tie sits where the table is ~0.3x the bytes of the rows
+            # a step touches (1.07 GB there); below 128 MB the dense path's image fits the caches and it is kept.
+            touched_bytes = self.batch_size * (3 + n_neg) * self.hidden_size * 4
+            threshold = getattr(self, "sparse_threshold_bytes", None)
+            if threshold is None:
+                threshold = max(128 << 20, int(0.3 * touched_bytes))
+            sparse = table_bytes > int(threshold)
+        return table_bytes, sparse
+
+    def _plan_entity_shard(self, model):
+        """If this process already belongs to a torch.distributed world of N > 1 ranks and the step will be the table-sharded
+        sparse one (TransE on the sign-count path, SGD or LazyAdam), the rows [lo, hi) of the entity table this rank will own:
+        the model then draws ONLY those rows (Model.embedding_def) instead of the whole table that _setup_shards would cut
+        down -- 102 GB per rank at BASELINE config #5.  None otherwise (the table is created whole, as before)."""
+        try:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                return None
+            W, g = dist.get_world_size(), dist.get_rank()
+        except Exception:
+            return None
+        if W <= 1 or W > 64 or self.hidden_size % 4:
+            return None
+        probe = model(config=self, define=False)
+        if probe.model_id != _lib.TRANSE or self.opt_method in ("Adam", "adam"):
+            return None
+        n_neg = self.negative_ent + self.negative_rel
+        desc = probe.descriptor()
+        if not (bool(getattr(self, "use_counts", True)) and bool(self.lib.kge_transe_counts_supported(ctypes.byref(desc), n_neg))):
+            return None
+        lazy = self.opt_method in ("LazyAdam", "lazyadam", "lazy_adam")
+        if not (bool(self._wants_sparse_rows(n_neg)[1]) or lazy):
+            return None
+        from .parallel import chunk_size
+        chunk = chunk_size(self.entTotal, W)
+        return dict(world=W, rank=g, chunk=chunk, lo=min(g * chunk, self.entTotal), hi=min((g + 1) * chunk, self.entTotal))
 
     # --- data-parallel partition: rank g owns virtual threads [g*W/G, (g+1)*W/G) ---
     def init_distributed(self, process_group=None):
@@ -463,6 +497,14 @@ class Config(object):
         W, g, E, D = self.world_size, self.rank, self.entTotal, self.hidden_size
         chunk = chunk_size(E, W)
         lo, hi = min(g * chunk, E), min((g + 1) * chunk, E)
+        if getattr(self, "_ent_is_shard", False):     # the model drew this rank's rows only (_plan_entity_shard); the moments were made shard-sized
+            plan = self._shard_plan
+            if (plan["world"], plan["rank"], plan["chunk"]) != (W, g, chunk) or self._tables[0].shape[0] != chunk:
+                raise KgeError("the entity table was created as the shard of rank %d of %d, the process group has rank %d of %d"
+                               % (plan["rank"], plan["world"], g, W))
+            self._shard = dict(chunk=chunk, lo=lo, hi=hi)
+            self._refresh_pointers()
+            return
         full = self._tables[0]
         shard = torch.zeros((chunk, D), dtype=torch.float32, device=full.device)
         if hi > lo:
@@ -767,6 +809,9 @@ class Config(object):
         '''
         import torch
         n_neg = self.negative_ent + self.negative_rel
+        if getattr(self, "_ent_is_shard", False) and not hasattr(self, "_shard"):
+            raise KgeError("the entity table was created as this rank's shard of a row-sharded table (the process belongs to a "
+                           "torch.distributed world): call init_distributed() before training")
         if batch_h is None:
             dev, n_pos = self._next_sampled_batch() if self.prefetch_sampling else self.sample_device()
             stride = max(self._n_local, 1)

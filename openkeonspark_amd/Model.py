@@ -29,19 +29,34 @@ def xavier_normal(rng, shape, fan_in=None):
 LARGE_TABLE_ELEMS = 1 << 28   # beyond 1 GiB of fp32 a table is initialised in HBM, never staged on the host
 
 
-def xavier_normal_device(shape, device, seed):
+def xavier_normal_device(shape, device, seed, row_range=None, out_rows=None):
     """Same distribution as xavier_normal, drawn by the device generator in row blocks (a 50M x 512
-    table is 102 GB: it exists only in HBM)."""
+    table is 102 GB: it exists only in HBM).  row_range=(lo, hi): only those rows are kept, in a tensor of `out_rows`
+    rows (a rank's shard of a row-sharded table: the generator still walks the whole table block by block, through one
+    512 MB scratch block, so every rank's rows are the rows of the single-process table -- but the table itself never exists)."""
     import torch
     rows, cols = shape
     std = float(np.sqrt(2.6 / (rows + cols)))
     gen = torch.Generator(device=device)
     gen.manual_seed(int(seed))
-    out = torch.empty(shape, dtype=torch.float32, device=device)
     block = max(1, (1 << 27) // max(cols, 1))
+    if row_range is None:
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+        for r0 in range(0, rows, block):
+            part = out[r0:r0 + block]
+            torch.nn.init.trunc_normal_(part, 0.0, std, -2.0 * std, 2.0 * std, generator=gen)   # inverse-CDF draw, in place
+        return out
+    lo, hi = row_range
+    out = torch.zeros((int(out_rows if out_rows is not None else hi - lo), cols), dtype=torch.float32, device=device)
+    scratch = torch.empty((min(block, rows), cols), dtype=torch.float32, device=device)
     for r0 in range(0, rows, block):
-        part = out[r0:r0 + block]
-        torch.nn.init.trunc_normal_(part, 0.0, std, -2.0 * std, 2.0 * std, generator=gen)   # inverse-CDF draw, in place
+        r1 = min(r0 + block, rows)
+        part = scratch[:r1 - r0]
+        torch.nn.init.trunc_normal_(part, 0.0, std, -2.0 * std, 2.0 * std, generator=gen)
+        a, b = max(lo, r0), min(hi, r1)
+        if b > a:
+            out[a - lo:b - lo].copy_(part[a - r0:b - r0])
+    del scratch
     return out
 
 
@@ -116,12 +131,24 @@ class Model(object):
         rng = np.random.default_rng(getattr(config, "seed", 0))
         device = getattr(config, "device", "cuda")
         self.parameter_lists = {}
+        plan = getattr(config, "_shard_plan", None)     # row-sharded entity table (Config._plan_entity_shard): this rank's rows only
         for name in self.table_names:
             shape = self.table_shapes()[name]
+            shard = plan if (plan is not None and name == "ent_embeddings") else None
             if int(np.prod(shape)) > LARGE_TABLE_ELEMS:
-                self.parameter_lists[name] = xavier_normal_device(shape, device, getattr(config, "seed", 0))
+                if shard is not None:
+                    self.parameter_lists[name] = xavier_normal_device(shape, device, getattr(config, "seed", 0),
+                                                                      row_range=(shard["lo"], shard["hi"]), out_rows=shard["chunk"])
+                else:
+                    self.parameter_lists[name] = xavier_normal_device(shape, device, getattr(config, "seed", 0))
             else:
-                self.parameter_lists[name] = torch.from_numpy(xavier_normal(rng, shape)).to(device)
+                full = xavier_normal(rng, shape)
+                if shard is not None:
+                    part = np.zeros((shard["chunk"], shape[1]), np.float32)
+                    part[:shard["hi"] - shard["lo"]] = full[shard["lo"]:shard["hi"]]
+                    full = part
+                self.parameter_lists[name] = torch.from_numpy(full).to(device)
+        config._ent_is_shard = plan is not None
         for name, t in self.parameter_lists.items():
             setattr(self, name, t)
 

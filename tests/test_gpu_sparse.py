@@ -198,3 +198,19 @@ def test_sparse_rows_request_off_the_count_path_takes_the_in_place_row_update(mo
     assert con.sparse_inplace and not con.sparse_rows and con._grads == []
     losses = [con.train_step() for _ in range(30)]
     assert all(np.isfinite(losses)) and np.mean(losses[-5:]) < np.mean(losses[:5])
+
+
+def test_shard_rows_drawn_directly_equal_the_rows_of_the_whole_table():
+    """A rank of the table-sharded mode draws ONLY its rows (Model.xavier_normal_device with row_range, through one scratch
+    block) -- they must be the rows the single-process table holds, or the union of the shards is not that table.
+    600 000 x 512 floats: beyond LARGE_TABLE_ELEMS, several generator blocks, a shard that straddles block boundaries."""
+    import torch
+    from openkeonspark_amd.Model import xavier_normal_device, LARGE_TABLE_ELEMS
+    shape = (600000, 512)
+    assert shape[0] * shape[1] > LARGE_TABLE_ELEMS
+    full = xavier_normal_device(shape, "cuda", 3)
+    for lo, hi, chunk in ((0, 150000, 150000), (150000, 450000, 300000), (450000, 600000, 150016)):
+        part = xavier_normal_device(shape, "cuda", 3, row_range=(lo, hi), out_rows=chunk)
+        assert part.shape == (chunk, 512)
+        assert torch.equal(part[:hi - lo], full[lo:hi])
+        assert not part[hi - lo:].any()
