@@ -995,6 +995,7 @@ class Config(object):
             n_pos, n_neg, stride, denom, self.batch_size, b["rec"].data_ptr(), b["dst"].data_ptr(), off, per,
             self._loss.data_ptr(), self._stream()), self.lib)
         if W > 1:
+            self.comm_fence("pg")
             all_gather_chunks(b["rec"].view(-1), b["rec"][off:off + per].view(-1), self._pg)
             all_gather_chunks(b["dst"], b["dst"][off:off + per], self._pg)
             allreduce_sum([self._loss], self._pg)
