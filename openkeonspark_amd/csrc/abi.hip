@@ -224,6 +224,8 @@ int kge_set_option(const char *name, INT value) {
     if (n == "counts_force_sort") { engine().counts_force_sort = value != 0; return KGE_OK; }
     if (n == "ride_shares") { engine().ride_shares = (int)value; return KGE_OK; }
     if (n == "transr_bf16x3") { engine().transr_bf16x3 = value != 0; return KGE_OK; }
+    if (n == "transr_groups") { engine().transr_groups = (int)value; return KGE_OK; }
+    if (n == "transr_fuse_vec") { engine().transr_fuse_vec = value != 0; return KGE_OK; }
     if (n == "transr_fused") { engine().transr_fused = value != 0; return KGE_OK; }
     if (n == "counts_fused") { engine().counts_fused = value != 0; return KGE_OK; }
     if (n == "counts_fused_diag") { engine().counts_fused_diag = (int)value; return KGE_OK; }

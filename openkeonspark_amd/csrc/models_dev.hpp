@@ -72,9 +72,10 @@ void guard_loss_stream(hipStream_t stream);   // loss partials / tickets are pro
 // Per-block partial hinge sums -> loss = sum / denom (TransE.py:51).  With a.loss_out set, the LAST block to
 // finish (ticket counter) adds the partials in the fixed order loss_finalize_kernel uses and writes the loss,
 // so no separate launch is needed; otherwise the partials are left for loss_finalize_kernel.
+// (finish_loss_sh: the 256-float scratch of the last workgroup's reduction is the caller's -- a kernel whose LDS budget has no
+// kilobyte to spare hands in a buffer it is done with)
 template <int TEAMS>
-__device__ __forceinline__ void finish_loss(const FbArgs &a, float *red, float lsum, int lane, int team_in_block) {
-    __shared__ float sh[256];
+__device__ __forceinline__ void finish_loss_sh(const FbArgs &a, float *red, float lsum, int lane, int team_in_block, float *sh) {
     __shared__ int is_last;
     const unsigned nblk = a.loss_blocks ? (unsigned)a.loss_blocks : gridDim.x;   // this kernel's own workgroups
     if (lane == 0) red[team_in_block] = lsum;
@@ -131,6 +132,12 @@ __device__ __forceinline__ void finish_loss(const FbArgs &a, float *red, float l
         }
         __hip_atomic_store(a.loss_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+template <int TEAMS>
+__device__ __forceinline__ void finish_loss(const FbArgs &a, float *red, float lsum, int lane, int team_in_block) {
+    __shared__ float sh[256];
+    finish_loss_sh<TEAMS>(a, red, lsum, lane, team_in_block, sh);
 }
 
 // one gradient row: atomic add into the dense accumulator, or (REC, m >= 0) a plain 4*D-byte record store

@@ -43,6 +43,8 @@ struct TrWork {
     int32_t *keys = nullptr, *keys2 = nullptr, *vals = nullptr, *vals2 = nullptr, *job_ent = nullptr, *row_ent = nullptr;
     int32_t *bucket_start = nullptr;  // [R+2]
     int32_t *tile_rel = nullptr, *tile_row0 = nullptr, *n_tiles = nullptr;
+    int32_t *bucket_rows = nullptr;   // group layout: start of every relation's ROW space ([R + 2]; bucket_start holds the group starts there)
+    int64_t cap_rel_rows = 0, pad_ready = -1;
     int32_t *bucket_start4 = nullptr, *tile_row0_4 = nullptr;   // fused tile path: the group-unit maps in ROW units (4 rows per group), for wgrad
     int64_t cap_rel4 = 0, cap_tiles4 = 0;
     int32_t *rel_hist = nullptr;      // two alternating pairs of [kRelBins] bucket sizes + [kRelBins] scatter cursors
@@ -80,7 +82,7 @@ int ensure_work(int64_t slots, int64_t dr, int64_t R) {
             if ((rc = hip_check(hipMalloc(&g_w.sort_tmp, bytes), "transr sort temp"))) return rc;
             g_w.sort_tmp_bytes = bytes;
         }
-        g_w.cap_slots = s; g_w.cap_dim = d;
+        g_w.cap_slots = s; g_w.cap_dim = d; g_w.pad_ready = -1;
     }
     if (R > g_w.cap_rel) {
         if ((rc = grow(g_w.bucket_start, (size_t)R + 2, "transr bucket_start"))) return rc;
@@ -128,6 +130,16 @@ __global__ void group_prep_kernel(const int32_t *__restrict__ br, long long n_po
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < 4 * n_pos; i += (long long)gridDim.x * blockDim.x) {
         if (i < n_pos) { keys[i] = br[i]; vals[i] = (int32_t)i; }
         iota4[i] = (int32_t)i;
+    }
+}
+
+// group layout: one key per GROUP (the positive's relation); also blanks the record keys of the row space (rows without a record)
+__global__ void group_keys_kernel(const int32_t *__restrict__ br, long long n_pos, int32_t *__restrict__ keys, int32_t *__restrict__ vals,
+                                  int32_t *__restrict__ rec_dst, long long n_rows) {
+    const long long n = n_pos > n_rows ? n_pos : n_rows;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (i < n_pos) { keys[i] = br[i]; vals[i] = (int32_t)i; }
+        if (rec_dst && i < n_rows) rec_dst[i] = -1;
     }
 }
 
@@ -192,7 +204,10 @@ __global__ __launch_bounds__(256) void rel_scatter_kernel(const int32_t *__restr
                                                           int32_t *__restrict__ hist, int32_t *__restrict__ cursor,
                                                           int32_t *__restrict__ sorted_vals, int32_t *__restrict__ bucket_start,
                                                           int32_t *__restrict__ tile_rel, int32_t *__restrict__ tile_row0,
-                                                          int32_t *__restrict__ n_tiles, int tile_shift, SamplerArgs ride, int n_own, int n_ride) {
+                                                          int32_t *__restrict__ n_tiles, int tile_shift, SamplerArgs ride, int n_own, int n_ride,
+                                                          int gps, int32_t *__restrict__ bucket_rows) {
+    // gps > 0 (group layout): the keys are groups; bucket_start stays in group units and the row space -- every relation's groups in
+    // sub-tiles of 16 rows holding gps groups each -- gets its own starts (bucket_rows, [R + 2]); the tile map is in ROW units
     // workgroups beyond the scatter's own carry the NEXT batch's sampler (kge_sampling_attach): this launch has a dozen to a
     // hundred workgroups and leaves the chip idle, the sampler is independent of everything in the step
     if ((int)blockIdx.x >= n_own) {
@@ -246,6 +261,49 @@ __global__ __launch_bounds__(256) void rel_scatter_kernel(const int32_t *__restr
     const int tile_rows = 1 << tile_shift;
     // relation r's bucket = its kRelSub sub-bins; thread t maps the relations t*RPT .. t*RPT + RPT-1
     constexpr int RPT = PER / kRelSub;
+    if (gps > 0) {
+        int rows_of[RPT], rows_mine = 0, tiles_g = 0;
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+            const int r = threadIdx.x * RPT + k;
+            rows_of[k] = r < R ? 16 * ((start[(r + 1) * kRelSub] - start[r * kRelSub] + gps - 1) / gps) : 0;
+            rows_mine += rows_of[k];
+            tiles_g += (rows_of[k] + tile_rows - 1) >> tile_shift;
+        }
+        __syncthreads();
+        part[threadIdx.x] = rows_mine;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int add = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        int row_run = part[threadIdx.x] - rows_mine;
+        const int rows_total = part[255];
+        __syncthreads();
+        part[threadIdx.x] = tiles_g;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int add = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        int tix = part[threadIdx.x] - tiles_g;
+        if (threadIdx.x == 255) n_tiles[0] = part[255];
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+            const int r = threadIdx.x * RPT + k;
+            if (r < R) {
+                bucket_rows[r] = row_run;
+                for (int row = row_run; row < row_run + rows_of[k]; row += tile_rows) { tile_rel[tix] = r; tile_row0[tix] = row; tix++; }
+                row_run += rows_of[k];
+            }
+        }
+        for (int r = R + (int)threadIdx.x; r <= R + 1; r += 256) bucket_rows[r] = rows_total;
+        return;
+    }
     int tiles_mine = 0;
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
@@ -313,6 +371,21 @@ struct GemmArgs {
     float *rec_out;
     int32_t *rec_dst;
     int32_t *row_ent;       // v3: entity of sorted job position p, written by the projection for wgrad3_kernel (one lookup instead of slot -> entity)
+    // group layout (sampler-shaped batches, negative_rel == 0, 2 + n <= 16): GROUPS, not (triple, side) jobs, are sorted by relation, and
+    // the U = 2 + n canonical rows of a group (h, t, the new entity of each negative) sit side by side inside one 16-row sub-tile of
+    // the relation's row space (gps = 16 / U groups per sub-tile, the rest of a sub-tile are pad rows: slot `pad_slot`, a zero GP row).
+    // The projection derives its rows from the sorted groups and writes sorted_slots / job_ent / row_ent for dgrad and wgrad.
+    const int32_t *sorted_groups, *group_start, *bh, *bt;
+    int32_t *sorted_slots_w, *job_ent_w;
+    long long n_pos, stride;
+    int U, gps, pad_slot;
+    // the vector stage inside the projection's epilogue (group layout): P never leaves the CU -- a group's projected rows lie side by
+    // side in the wave's LDS staging block; what the projection stores is GP (TransR.py:19-23, Model.py loss, backward through the
+    // normalisation), the loss partial goes through finish_loss (fb), the relation gradient as one row of atomics per wave and tile
+    int fuse_vec;
+    const float *rel;
+    float *g_rel, *GP_w;
+    FbArgs fb;
 };
 
 template <int MODE>
@@ -755,9 +828,14 @@ __global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
     constexpr int BIMG = 3 * NCOL * 64;      // bytes of one B image
     constexpr int LDC = NCOL + 4;            // output staging row (floats): 4 (mod 8), the transposing writes of a half-wave hit 32 banks
     const int tile = blockIdx.x;
-    if (tile >= a.n_tiles[0]) return;
+    __shared__ float red_loss[4];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * BIMG];
     __shared__ int s_slot[RW3], s_ent[RW3];
+    if (tile >= a.n_tiles[0]) {
+        if (MODE == GEMM_PROJECT && a.fuse_vec)     // every workgroup reports a loss partial
+            finish_loss_sh<4>(a.fb, red_loss, 0.f, threadIdx.x & 63, threadIdx.x >> 6, reinterpret_cast<float *>(Bs));
+        return;
+    }
     const int r = a.tile_rel[tile];
     const int row0 = a.tile_row0[tile];
     const int rows = min(RW3, a.bucket_start[r + 1] - row0);
@@ -826,9 +904,35 @@ __global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
     };
     KGE_LOADB3(0)            // the matrix does not depend on the index chain below
     if (tid < RW3) {
-        const int sl = a.sorted_slots[row0 + min(tid, rows - 1)];     // padding rows repeat the last live row (never stored)
-        s_slot[tid] = sl;
-        s_ent[tid] = a.job_ent[sl];
+        if (MODE == GEMM_PROJECT && a.sorted_groups) {
+            // group layout: row -> (sub-tile, group in it, member u): u = 0 the head, 1 the tail, 1 + k the new entity of negative k
+            const int rel_row = row0 + tid - a.bucket_start[r];
+            const int w = rel_row & 15, q = w / a.U, u = w - q * a.U;
+            const int gi = (rel_row >> 4) * a.gps + q;
+            const int g0 = a.group_start[r];
+            int sl = a.pad_slot, e = 0;
+            if (tid < rows && q < a.gps && gi < a.group_start[r + 1] - g0) {
+                const long long b = a.sorted_groups[g0 + gi];
+                const int h = a.bh[b];
+                if (u == 0) { sl = (int)(2 * b); e = h; }
+                else if (u == 1) { sl = (int)(2 * b + 1); e = a.bt[b]; }
+                else {
+                    const long long j = b + (long long)(u - 1) * a.stride;
+                    const int nh = a.bh[j];
+                    const bool new_head = nh != h;
+                    sl = (int)(2 * ((long long)(u - 1) * a.n_pos + b) + (new_head ? 0 : 1));
+                    e = new_head ? nh : a.bt[j];
+                }
+                a.job_ent_w[sl] = e;
+            }
+            s_slot[tid] = sl;
+            s_ent[tid] = e;
+            if (tid < rows) a.sorted_slots_w[row0 + tid] = sl;
+        } else {
+            const int sl = a.sorted_slots[row0 + min(tid, rows - 1)];     // padding rows repeat the last live row (never stored)
+            s_slot[tid] = sl;
+            s_ent[tid] = a.job_ent[sl];
+        }
     }
     __syncthreads();
     const float *arow[RT2];
@@ -889,7 +993,8 @@ __global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
 #undef KGE_LOADA3
 #undef KGE_LOADB3
 #undef KGE_PUTB3
-    if (MODE == GEMM_DGRAD && a.rec_out && tid < rows) a.rec_dst[row0 + tid] = s_ent[tid];
+    const bool has_pads = a.sorted_groups != nullptr;           // group layout: rows of slot a.pad_slot carry nothing
+    if (MODE == GEMM_DGRAD && a.rec_out && tid < rows) a.rec_dst[row0 + tid] = has_pads && s_slot[tid] == a.pad_slot ? -1 : s_ent[tid];
     if (MODE == GEMM_PROJECT && a.row_ent && tid < rows) a.row_ent[row0 + tid] = s_ent[tid];
     if (MODE == GEMM_DGRAD && !a.rec_out) {            // small steps: fp32 atomics straight from the accumulators
 #pragma unroll
@@ -902,7 +1007,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
 #pragma unroll
                     for (int v = 0; v < 4; v++) {
                         const int row = (4 * s2 + wave) * 16 + 4 * g + v;
-                        if (row < rows) __builtin_amdgcn_global_atomic_fadd_f32(
+                        if (row < rows && !(has_pads && s_slot[row] == a.pad_slot)) __builtin_amdgcn_global_atomic_fadd_f32(
                                 (__attribute__((address_space(1))) float *)(a.g_ent + (long long)s_ent[row] * a.De + j), acc[s2][t][v]);
                     }
                 }
@@ -913,6 +1018,153 @@ __global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
     // rows out through LDS (the B images are free: every wave is past the last barrier): wave-private 16 x LDC staging
     float *Cs = reinterpret_cast<float *>(Bs) + wave * 16 * LDC;
     const int qn = ncols >> 2;
+    if (MODE == GEMM_PROJECT && a.fuse_vec) {
+        // ---- the vector stage on the staged rows.  FOUR groups at a time: the 16 lanes of a DPP row are a team, lane l16 of it holds
+        // columns l16, l16 + 16, ... of its group's rows (NT per row), every reduction is four DPP adds inside the row and serves four
+        // groups.  The rows are turned into their gradients IN PLACE in the staging block, which then leaves as GP rows. ----
+        const int Dr = a.Dr;
+        const int team = lane >> 4, l16 = lane & 15;
+        bool cv[NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++) cv[j] = l16 + 16 * j < Dr;
+        auto ldrow = [&](const float *p, float (&x)[NT]) {
+#pragma unroll
+            for (int j = 0; j < NT; j++) x[j] = cv[j] ? p[l16 + 16 * j] : 0.f;
+        };
+        auto dotT = [&](const float (&x)[NT], const float (&y)[NT]) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; j++) sdot += x[j] * y[j];
+            return team_sum<16>(sdot);
+        };
+        auto normalizeT = [&](float (&x)[NT], float &inv, bool &uc) {
+            const float ss = dotT(x, x);
+            uc = ss >= 1e-12f;
+            inv = 1.0f / sqrtf(uc ? ss : 1e-12f);
+#pragma unroll
+            for (int j = 0; j < NT; j++) x[j] *= inv;
+        };
+        const float unit = a.fb.unit;
+        // gx = inv (unit G - y <y, unit G>), written over gv
+        auto normalize_bwdT = [&](const float (&y)[NT], float (&gv)[NT], float inv, bool uc) {
+            float d = dotT(y, gv) * unit;
+            if (!uc) d = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; j++) gv[j] = inv * (unit * gv[j] - d * y[j]);
+        };
+        float *s_grel = reinterpret_cast<float *>(Bs) + 4 * 16 * LDC;      // behind the four waves' staging blocks: the tile's relation sign sums
+        for (int i = tid; i < NCOL; i += 256) s_grel[i] = 0.f;
+        __syncthreads();
+        float rn[NT], Sr[NT];
+        float inv_r; bool uc_r;
+#pragma unroll
+        for (int j = 0; j < NT; j++) { rn[j] = cv[j] ? a.rel[(long long)r * Dr + l16 + 16 * j] : 0.f; Sr[j] = 0.f; }
+        normalizeT(rn, inv_r, uc_r);
+        float lsum = 0.f;
+        const int n_groups_r = a.group_start[r + 1] - a.group_start[r];
+        const int rel_row0 = row0 - a.bucket_start[r];
+        const int U = a.U, gps = a.gps;
+#pragma unroll
+        for (int s2 = 0; s2 < RT2; s2++) {
+            const int base = (4 * s2 + wave) * 16;
+            if (base >= rows) continue;
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) Cs[(4 * g + v) * LDC + 16 * t + r16] = acc[s2][t][v];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int live_groups = min(gps, n_groups_r - ((rel_row0 + base) >> 4) * gps);      // >= 1: the sub-tile exists
+            for (int q0 = 0; q0 < live_groups; q0 += 4) {
+                const bool active = q0 + team < live_groups;
+                const int q = active ? q0 + team : live_groups - 1;         // idle teams shadow the last group (nothing stored)
+                float *rowp = Cs + (q * U) * LDC;
+                float hn[NT], tn[NT];
+                float inv_h, inv_t; bool uc_h, uc_t;
+                ldrow(rowp, hn); ldrow(rowp + LDC, tn);
+                normalizeT(hn, inv_h, uc_h); normalizeT(tn, inv_t, uc_t);
+                float gh[NT], gt[NT], sp_keep[NT];     // dL/d(h^, t^) / unit: integer sign sums (r^'s is gh - gt - cnt sp); the positive's signs
+                float pacc = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; j++) { const float ev = hn[j] + rn[j] - tn[j]; pacc += fabsf(ev); sp_keep[j] = sgn(ev); gh[j] = 0.f; gt[j] = 0.f; }
+                const float pscore = team_sum<16>(pacc);
+                int cnt = 0;
+                for (int k = 0; k < U - 2; k++) {
+                    const bool new_head = (s_slot[base + q * U + 2 + k] & 1) == 0;      // the corrupted side's slot: even = head side
+                    float xn[NT], sg[NT];
+                    float inv; bool uc;
+                    ldrow(rowp + (2 + k) * LDC, xn);
+                    normalizeT(xn, inv, uc);
+                    float nacc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NT; j++) {
+                        const float ev = new_head ? xn[j] + rn[j] - tn[j] : hn[j] + rn[j] - xn[j];
+                        nacc += fabsf(ev); sg[j] = sgn(ev);
+                    }
+                    const float hv = pscore - team_sum<16>(nacc) + a.fb.margin;
+                    const bool on = hv >= 0.f;                                          // tf.maximum routes a tie to the hinge
+                    if (on && active && l16 == 0) lsum += hv;
+                    cnt += on ? 1 : 0;
+#pragma unroll
+                    for (int j = 0; j < NT; j++) {
+                        const float sj = on ? sg[j] : 0.f;
+                        if (new_head) gt[j] += sj; else gh[j] -= sj;
+                        sg[j] = new_head ? -sj : sj;
+                    }
+                    normalize_bwdT(xn, sg, inv, uc);                                    // (an inactive hinge: zeros in, zeros out)
+                    if (active) {
+#pragma unroll
+                        for (int j = 0; j < NT; j++) if (cv[j]) rowp[(2 + k) * LDC + l16 + 16 * j] = sg[j];
+                    }
+                }
+                const float fc = (float)cnt;
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    gh[j] += fc * sp_keep[j]; gt[j] -= fc * sp_keep[j];
+                    if (active) Sr[j] += gh[j] - gt[j] - fc * sp_keep[j];      // = -(all the negatives' signs) + cnt sp
+                }
+                normalize_bwdT(hn, gh, inv_h, uc_h);
+                normalize_bwdT(tn, gt, inv_t, uc_t);
+                if (active) {
+#pragma unroll
+                    for (int j = 0; j < NT; j++)
+                        if (cv[j]) { rowp[l16 + 16 * j] = gh[j]; rowp[LDC + l16 + 16 * j] = gt[j]; }
+                }
+            }
+            if (lane < 16 && a.row_ent) a.row_ent[row0 + base + lane] = s_ent[base + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int idx = lane; idx < 16 * qn; idx += 64) {             // the gradients out as GP rows (pad rows keep the pad slot's zeros)
+                const int rl = idx / qn, q4 = idx - rl * qn;
+                const int sl = s_slot[base + rl];
+                if (base + rl < rows && sl != a.pad_slot)
+                    *reinterpret_cast<float4 *>(a.GP_w + (long long)sl * Dr + 4 * q4) = *reinterpret_cast<const float4 *>(&Cs[rl * LDC + 4 * q4]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+#pragma unroll
+        for (int j = 0; j < NT; j++) if (cv[j] && Sr[j] != 0.f) atomicAdd(&s_grel[l16 + 16 * j], Sr[j]);
+        const float wsum = team_sum<64>(l16 == 0 ? lsum : 0.f);        // the wave's hinge sum (the four teams' lane 0)
+        __syncthreads();                                               // s_grel complete; every wave is done with its staging rows
+        if (wave == 0) {   // g_rel[r] += inv_r (unit S - unit <r^, S> r^): the normalise-backward is linear in S, so once per tile
+            float Sg[NT];
+#pragma unroll
+            for (int j = 0; j < NT; j++) Sg[j] = cv[j] ? s_grel[l16 + 16 * j] : 0.f;
+            normalize_bwdT(rn, Sg, inv_r, uc_r);
+            if (team == 0) {
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+                    if (cv[j] && Sg[j] != 0.f) __builtin_amdgcn_global_atomic_fadd_f32(
+                            (__attribute__((address_space(1))) float *)(a.g_rel + (long long)r * Dr + l16 + 16 * j), Sg[j]);
+            }
+        }
+        finish_loss_sh<4>(a.fb, red_loss, wsum, lane, wave, reinterpret_cast<float *>(Bs));
+        return;
+    }
 #pragma unroll
     for (int s2 = 0; s2 < RT2; s2++) {
         const int base = (4 * s2 + wave) * 16;
@@ -1676,7 +1928,7 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
             if (upload_jump_table() == KGE_OK && !take_attached_sampler(ride, n_ride)) n_ride = 0;
             hipLaunchKernelGGL(rel_scatter_kernel, dim3(tiles + n_ride), dim3(256), 0, stream, g_w.keys, g_w.vals, (int)n_pos, (int)R, pair,
                                pair + kRelBins, g_w.vals2, g_w.bucket_start, g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, 5, ride,
-                               (int)tiles, (int)n_ride);
+                               (int)tiles, (int)n_ride, 0, (int32_t *)nullptr);
             FusedArgs fa = {};
             fa.ent = tables[0]; fa.mat = tables[2]; fa.rel = tables[1]; fa.g_ent = grads[0]; fa.g_rel = grads[1];
             fa.bh = d_h; fa.bt = d_t; fa.br = d_r; fa.n_pos = n_pos; fa.stride = stride;
@@ -1694,7 +1946,7 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
                 rs.g_ent = grads[0]; rs.E = m.ent_total; rs.R = 0; rs.hub_base = m.ent_total; rs.hub_rows = 1; rs.rows = m.ent_total;
                 if ((rc = float_records_reduce(rows4, De, rs, stream))) return rc;
             }
-            GemmArgs gw;
+            GemmArgs gw = {};
             gw.ent = tables[0]; gw.mat = tables[2]; gw.GP = g_w.GP; gw.P = nullptr; gw.g_ent = grads[0];
             gw.sorted_slots = g_w.keys2; gw.job_ent = g_w.job_ent; gw.bucket_start = g_w.bucket_start4;
             gw.tile_rel = g_w.tile_rel; gw.tile_row0 = g_w.tile_row0_4; gw.n_tiles = g_w.n_tiles;
@@ -1703,6 +1955,95 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
             const dim3 wg2((unsigned)((tiles32 + span - 1) / span), 2);
             hipLaunchKernelGGL(wgrad2_kernel, wg2, dim3(256), 0, stream, gw, grads[2], span);
             return hip_check(hipGetLastError(), "transr fused launch");
+        }
+    }
+    // ---- group layout (GemmArgs): device-sampled batches with the positive's matrix for every negative, 2 + n <= 16 rows per group ----
+    {
+        const int U = 2 + (int)n_neg;
+        const bool v3g = v2 && engine().transr_bf16x3 && engine().transr_v1 == 0 && engine().transr_groups;
+        // well-filled buckets only (the same bound as wgrad's spans): at the reference's own batch (~46 rows per relation) the longer
+        // epilogue of the one tile a relation has costs more than the vector-stage launch it replaces (192 vs 177 us at B = 2 721);
+        // transr_groups = 2 takes the layout at any size (tests)
+        const bool big = n_pos * U >= 64 * R || engine().transr_groups == 2;
+        if (v3g && big && sampler_shaped && m.negative_rel == 0 && U <= 16 && (R + 1) * kRelSub <= kRelBins && !engine().counts_force_sort) {
+            const int gps = 16 / U;
+            const int64_t rows_max = 16 * ((n_pos + gps - 1) / gps + R + 1);       // sum over relations of 16 ceil(groups / gps)
+            if ((rc = ensure_work(slots + 1 > rows_max ? slots + 1 : rows_max, Dr, R))) return rc;
+            if (R + 2 > g_w.cap_rel_rows) { if ((rc = grow(g_w.bucket_rows, (size_t)R + 2, "transr bucket_rows"))) return rc; g_w.cap_rel_rows = R + 2; }
+            if (g_w.pad_ready != slots) {     // the pad slot: a zero GP row, entity 0 (never written by the vector stage)
+                if ((rc = hip_check(hipMemsetAsync(g_w.GP + (size_t)slots * Dr, 0, sizeof(float) * (size_t)Dr, stream), "zero pad GP row"))) return rc;
+                if ((rc = hip_check(hipMemsetAsync(g_w.job_ent + slots, 0, sizeof(int32_t), stream), "pad entity"))) return rc;
+                g_w.pad_ready = slots;
+            }
+            float *drec = nullptr;
+            int32_t *ddst = nullptr;
+            const bool records = engine().transr_dgrad_records && slots >= engine().transr_dgrad_records_min;
+            if (records && (rc = float_records_workspace(rows_max, De, drec, ddst))) return rc;
+            const int64_t span_n = n_pos > rows_max ? n_pos : (records ? rows_max : n_pos);
+            int gb = (int)((span_n + 255) / 256);
+            if (gb > 4096) gb = 4096;
+            hipLaunchKernelGGL(group_keys_kernel, dim3(gb), dim3(256), 0, stream, d_r, (long long)n_pos, g_w.keys, g_w.vals, ddst,
+                               (long long)(records ? rows_max : 0));
+            if (!g_w.rel_hist) {
+                if ((rc = grow(g_w.rel_hist, 4 * (size_t)kRelBins, "transr relation histogram"))) return rc;
+                if ((rc = hip_check(hipMemset(g_w.rel_hist, 0, sizeof(int32_t) * 4 * kRelBins), "zero relation histogram"))) return rc;
+            }
+            int32_t *pair = g_w.rel_hist + (g_w.rel_parity ? 2 * kRelBins : 0), *other = g_w.rel_hist + (g_w.rel_parity ? 0 : 2 * kRelBins);
+            g_w.rel_parity ^= 1;
+            const unsigned tiles = (unsigned)((n_pos + kRelTile - 1) / kRelTile);
+            hipLaunchKernelGGL(rel_count_kernel, dim3(tiles), dim3(256), 0, stream, g_w.keys, (int)n_pos, ((int)R + 1) * kRelSub, pair, other);
+            SamplerArgs ride = {};
+            unsigned n_ride = 0;
+            if (upload_jump_table() == KGE_OK && !take_attached_sampler(ride, n_ride)) n_ride = 0;
+            hipLaunchKernelGGL(rel_scatter_kernel, dim3(tiles + n_ride), dim3(256), 0, stream, g_w.keys, g_w.vals, (int)n_pos, (int)R, pair,
+                               pair + kRelBins, g_w.keys2, g_w.bucket_start, g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, 7, ride,
+                               (int)tiles, (int)n_ride, gps, g_w.bucket_rows);
+            GemmArgs ga = {};
+            ga.ent = tables[0]; ga.mat = tables[2]; ga.GP = g_w.GP; ga.P = g_w.P; ga.g_ent = grads[0];
+            ga.sorted_slots = g_w.vals2; ga.job_ent = g_w.job_ent; ga.bucket_start = g_w.bucket_rows;
+            ga.tile_rel = g_w.tile_rel; ga.tile_row0 = g_w.tile_row0; ga.n_tiles = g_w.n_tiles;
+            ga.De = De; ga.Dr = Dr;
+            ga.rec_out = drec; ga.rec_dst = ddst; ga.row_ent = g_w.row_ent;
+            ga.sorted_groups = g_w.keys2; ga.group_start = g_w.bucket_start; ga.bh = d_h; ga.bt = d_t;
+            ga.sorted_slots_w = g_w.vals2; ga.job_ent_w = g_w.job_ent; ga.n_pos = n_pos; ga.stride = stride;
+            ga.U = U; ga.gps = gps; ga.pad_slot = (int)slots;
+            const unsigned max_tiles = (unsigned)(rows_max / RW3 + R + 1);
+            // the vector stage in the projection's epilogue: widths the one-float4-per-lane layout covers, a grid the loss hand-off can count
+            const bool fuse = engine().transr_fuse_vec && Dr <= 256 && max_tiles <= (unsigned)kMaxLossBlocks;
+            if (fuse) {
+                if ((rc = ensure_loss_buffers())) return rc;
+                guard_loss_stream(stream);
+                ga.fuse_vec = 1; ga.rel = tables[1]; ga.g_rel = grads[1]; ga.GP_w = g_w.GP;
+                ga.fb.loss_partials = engine().dev.loss_partials; ga.fb.loss_out = d_loss; ga.fb.loss_ticket = engine().dev.loss_ticket;
+                ga.fb.unit = 1.0f / (float)denom; ga.fb.margin = m.margin;
+            }
+            if (Dr <= 112) hipLaunchKernelGGL((rows_gemm3_kernel<GEMM_PROJECT, 7>), dim3(max_tiles), dim3(256), 0, stream, ga);
+            else hipLaunchKernelGGL((rows_gemm3_kernel<GEMM_PROJECT, 13>), dim3(max_tiles), dim3(256), 0, stream, ga);
+            if (!fuse) {
+                const bool lean = transr_lean_vector_stage(Dr);
+                if (!lean && (rc = hip_check(hipMemsetAsync(g_w.GP, 0, sizeof(float) * (size_t)slots * Dr, stream), "zero GP"))) return rc;
+                rc = launch_transr_vector_stage(tables[1], grads[1], g_w.P, g_w.GP, d_h, d_t, d_r, n_pos, n_neg, stride, denom, Dr, m.margin,
+                                                m.negative_rel, d_loss, stream, lean, sampler_shaped, R);
+                if (rc) return rc;
+            }
+            if (De <= 112) hipLaunchKernelGGL((rows_gemm3_kernel<GEMM_DGRAD, 7>), dim3(max_tiles), dim3(256), 0, stream, ga);
+            else hipLaunchKernelGGL((rows_gemm3_kernel<GEMM_DGRAD, 13>), dim3(max_tiles), dim3(256), 0, stream, ga);
+            if (records) {
+                FloatRowSpace rs = {};
+                rs.g_ent = grads[0]; rs.E = m.ent_total; rs.R = 0; rs.hub_base = m.ent_total; rs.hub_rows = 1; rs.rows = m.ent_total;
+                if ((rc = float_records_reduce(rows_max, De, rs, stream))) return rc;
+            }
+            if (De > 192 && Dr > 192) {
+                const int span = rows_max >= 256 * R ? SPAN2 : 1;
+                const dim3 wg2((max_tiles + span - 1) / span, 2);
+                hipLaunchKernelGGL(wgrad3_kernel, wg2, dim3(256), 0, stream, ga, grads[2], span);
+            } else {
+                const int tiles_i1 = (De + 31) / 32;
+                const int wgt = WG_TILES * 32 / RW2;
+                const unsigned groups1 = (max_tiles + wgt - 1) / wgt;
+                hipLaunchKernelGGL(wgrad_kernel, dim3(groups1 * tiles_i1, (Dr + TN - 1) / TN), dim3(256), 0, stream, ga, grads[2], tiles_i1, RW2, wgt);
+            }
+            return hip_check(hipGetLastError(), "transr launch (group layout)");
         }
     }
     // dgrad's entity-gradient rows as float records + segmented sum instead of atomics: from 32 768 slots on (below that the
@@ -1728,7 +2069,7 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
         if (upload_jump_table() == KGE_OK && !take_attached_sampler(ride, n_ride)) n_ride = 0;
         hipLaunchKernelGGL(rel_scatter_kernel, dim3(tiles + n_ride), dim3(256), 0, stream, g_w.keys, g_w.vals, (int)slots, (int)R, pair,
                            pair + kRelBins, g_w.vals2, g_w.bucket_start, g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, v2 ? 7 : 5, ride,
-                           (int)tiles, (int)n_ride);
+                           (int)tiles, (int)n_ride, 0, (int32_t *)nullptr);
     } else {
         size_t tmp = g_w.sort_tmp_bytes;
         rc = hip_check(rocprim::radix_sort_pairs(g_w.sort_tmp, tmp, g_w.keys, g_w.keys2, g_w.vals, g_w.vals2, (size_t)slots, 0,
@@ -1737,7 +2078,7 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
         hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(1024), 0, stream, g_w.keys2, (int)slots, (int)R, g_w.bucket_start,
                            g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, v2 ? 7 : 5);
     }
-    GemmArgs ga;
+    GemmArgs ga = {};
     ga.ent = tables[0]; ga.mat = tables[2]; ga.GP = g_w.GP; ga.P = g_w.P; ga.g_ent = grads[0];
     ga.sorted_slots = g_w.vals2; ga.job_ent = g_w.job_ent; ga.bucket_start = g_w.bucket_start;
     ga.tile_rel = g_w.tile_rel; ga.tile_row0 = g_w.tile_row0; ga.n_tiles = g_w.n_tiles;
