@@ -45,3 +45,8 @@ grep -a "^{" $out/config5.log | tail -1 > $out/config5_one_gpu.json
 python3 tools/rocpd_stats.py $out/kt5/r_results.db $out/kernel_stats_config5.csv
 rm -rf $out/kt5
 echo "config5 done"
+cd /tmp
+timeout -k 10 600 python3 $GRAFT_REPO_ROOT/tools/bench_sparse.py --entities 50000000 --relations 1000 --triples 500000000 --dim 512 --batch 1050420 --neg 1 --steps 8 --ent-exponent 0 > $GRAFT_REPO_ROOT/$out/config5_500M.log 2>&1 || true
+cd $GRAFT_REPO_ROOT
+grep -a "^{" $out/config5_500M.log | tail -1 > $out/config5_one_gpu_500M_triples.json
+echo "config5 500M done"
