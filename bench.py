@@ -489,7 +489,7 @@ def main():
                        "optimizer": "Adam(dense, TF1 parity)", "gradient_path": "int8 sign-count records (exact)",
                        "work_threads": WORK_THREADS,
                        "parallelism": "dp%d" % world, "final_loss": loss},
-            "roofline": {"bound": "hbm", "kernel": "kge::transe_emit_vec_kernel<64,1,4,1,true>",
+            "roofline": {"bound": "hbm", "kernel": "kge::transe_emit_vec_kernel<64,1,4,1,true,true>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note, "kernel_ms": kern_ms,
                          "kernel_launches_timed": int(timed.value), "kernel_launches_timed_inside_region": min(in_region, int(timed.value)),
