@@ -1367,19 +1367,26 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(GemmArgs a, float *__res
 // ---------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int WK3 = 32;
+// image rows: the X half 10 segments of 32 B (7 of columns + 3 of rotation: 320 B), GP 16 (13 + 3: 512 B).  The segment of row k is
+// rotated by k & 3 only and never wraps, so every address is (a per-lane base) + (a compile-time offset): the kernel is bound by
+// instruction issue (20 % of its wave cycles active, 16 % matrix pipe), and with a wrapping rotation every one of a chunk's 90
+// fragment reads and 33 staging writes recomputed its segment -- some 1 500 of the ~2 000 vector instructions of a chunk.  (Rows
+// 8 apart now share their bank group: the transposed reads of a 32-lane half are 2-way conflicted; the LDS array is not the limit.)
+constexpr int XROWB = 320, GROWB = 512;
+constexpr int XTERM = WK3 * XROWB, GTERM = WK3 * GROWB;     // bytes of one term plane
 
-__device__ __forceinline__ int img3_off(int nseg_log2, int term, int k, int c) {      // byte offset of columns c .. c + 3 (c % 4 == 0) of row k
-    const int rot = (k & 3) | (((k >> 3) & 1) << 2);
-    const int seg = ((c >> 4) + rot) & ((1 << nseg_log2) - 1);
-    return ((((term << 5) + k) << nseg_log2) + seg) * 32 + (c & 15) * 2;
+// byte offset of columns c .. c + 3 (c % 4 == 0) of row k of term plane t:  t * term_bytes + k * rowb + 32 (c / 16 + (k & 3)) + 2 (c % 16)
+// a lane's base for the fragments of k-rows 8G .. 8G+7: lane 4q + p of a 16-lane group addresses row 8G + q (+ 4 for the second read),
+// columns 4p .. of the tile; tile t of term `term`: + term * term_bytes + 32 t, the second read + 4 * rowb -- all compile-time
+__device__ __forceinline__ int frag3_base(int rowb, int lane) {
+    const int r16 = lane & 15, q = r16 >> 2, pp = r16 & 3, G = lane >> 4;
+    return (8 * G + q) * rowb + (q << 5) + 8 * pp;
 }
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char *img, int nseg_log2, int term, int kbase, int c0, int lane) {
-    // lane 4q + p of a 16-lane group addresses row kbase + q, columns c0 + 4p ..; it receives column c0 + (lane & 15), rows kbase .. + 3
-    const int r16 = lane & 15, q = r16 >> 2, pp = r16 & 3;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4 *)(img + img3_off(nseg_log2, term, kbase + q, c0 + 4 * pp)));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4 *)(img + img3_off(nseg_log2, term, kbase + 4 + q, c0 + 4 * pp)));
+template <int ROWB, int TERMB>
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char *lane_base, int term, int tile) {
+    const unsigned char *p = lane_base + term * TERMB + tile * 32;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p + 4 * ROWB));
     const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
     return __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
 }
@@ -1389,8 +1396,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(GemmArgs a, float *__res
     const int t0 = blockIdx.x * span;
     if (t0 >= n_tiles) return;
     const int t1 = min(t0 + span, n_tiles);
-    __shared__ __attribute__((aligned(16))) unsigned char Xs[3 * WK3 * 256];
-    __shared__ __attribute__((aligned(16))) unsigned char Gs[3 * WK3 * 512];
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[3 * XTERM];
+    __shared__ __attribute__((aligned(16))) unsigned char Gs[3 * GTERM];
     __shared__ int s_ids[2][WK3];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1413,11 +1420,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(GemmArgs a, float *__res
     const int cq80 = tid % QROW, k0 = tid / QROW;              // k0 = 3: no tasks
     const bool isx = cq80 < LDX2 / 4;
     const int cq = isx ? cq80 : cq80 - LDX2 / 4;
-    const bool col_ok = cq < (isx ? qx : qg);
     const float *tab = isx ? a.ent + i0 + 4 * min(cq, qx - 1) : a.GP + 4 * min(cq, qg - 1);
     const long long ld = isx ? a.De : a.Dr;
-    unsigned char *img = isx ? Xs : Gs;
-    const int lg = isx ? 3 : 4;
+    // this thread's column part of every staging address; the row part of task u (row k0 + 3 u) is k * rowb + 32 (k & 3)
+    unsigned char *img = (isx ? Xs : Gs) + (((4 * cq) >> 4) << 5) + ((4 * cq) & 15) * 2;
+    const int rowb = isx ? XROWB : GROWB, termb = isx ? XTERM : GTERM;
     // chunk descriptors: the one being multiplied (d0), the one whose data is in flight (d1), the one whose ids are in flight (d2)
     struct Chunk { int row_first, crow, rel, t, c; bool valid; };
     auto chunk_at = [&](int t, int c) {
@@ -1464,13 +1471,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(GemmArgs a, float *__res
                 constexpr int u = decltype(uc)::value;
                 const int k = k0 + 3 * u;
                 if (u < NTASK - 1 || k < WK3) {
-                    const float4 v = keep_if(k < d.crow && col_ok, rs[u]);
+                    // columns beyond the table's width hold clamped duplicates: they only reach output rows / columns that are never
+                    // stored.  Rows beyond the chunk must be zero (a short last chunk: the rare, wave-uniform case).
+                    const float4 v = d.crow == WK3 ? rs[u] : keep_if(k < d.crow, rs[u]);
                     uint2 p1, p2, p3;
                     split3_pair(v.x, v.y, p1.x, p2.x, p3.x);
                     split3_pair(v.z, v.w, p1.y, p2.y, p3.y);
-                    *reinterpret_cast<uint2 *>(img + img3_off(lg, 0, k, 4 * cq)) = p1;
-                    *reinterpret_cast<uint2 *>(img + img3_off(lg, 1, k, 4 * cq)) = p2;
-                    *reinterpret_cast<uint2 *>(img + img3_off(lg, 2, k, 4 * cq)) = p3;
+                    unsigned char *dst = img + k * rowb + ((k & 3) << 5);
+                    *reinterpret_cast<uint2 *>(dst) = p1;
+                    *reinterpret_cast<uint2 *>(dst + termb) = p2;
+                    *reinterpret_cast<uint2 *>(dst + 2 * termb) = p3;
                 }
             });
         }
@@ -1506,7 +1516,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(GemmArgs a, float *__res
     load_data(d0);
     load_ids(d1);
     bool first = true;
-    const int G4 = lane >> 4;
+    const unsigned char *xbase = Xs + frag3_base(XROWB, lane), *gbase = Gs + frag3_base(GROWB, lane);
     while (true) {
         if (!first) __syncthreads();          // the previous chunk's fragment reads (and its readers of s_ids) are done
         first = false;
@@ -1524,11 +1534,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(GemmArgs a, float *__res
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
-                for (int t = 0; t < 3; t++) af[s2][t] = tr_frag(Xs, 3, t, 8 * G4, min(wave + 4 * s2, WH2 - 1) * 16, lane);
+                for (int t = 0; t < 3; t++) af[s2][t] = tr_frag<XROWB, XTERM>(xbase, t, min(wave + 4 * s2, WH2 - 1));
             bf16x8 bf[2][3];
             auto fetch = [&](int buf, int jt) {
 #pragma unroll
-                for (int t = 0; t < 3; t++) bf[buf][t] = tr_frag(Gs, 4, t, 8 * G4, jt * 16, lane);
+                for (int t = 0; t < 3; t++) bf[buf][t] = tr_frag<GROWB, GTERM>(gbase, t, jt);
             };
             fetch(0, 0);
             static_for<0, NT2>([&](auto tc) {
