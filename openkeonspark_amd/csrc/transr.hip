@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
                 float4 m[8];
                 static_for<0, 8>([&](auto ec) {
                     constexpr int e = decltype(ec)::value;
-                    m[e] = keep_if(k0 + 8 * pq + e < K, rb[e]);
+                    m[e] = keep_if(k0 + 8 * pq + e < K && 4 * pj < ncols, rb[e]);      // (columns beyond the width: zero, so that the padding columns of P are)
                 });
                 { const float v[8] = {m[0].x, m[1].x, m[2].x, m[3].x, m[4].x, m[5].x, m[6].x, m[7].x}; KGE_PUTB3(4 * pj, pq, v) }
                 { const float v[8] = {m[0].y, m[1].y, m[2].y, m[3].y, m[4].y, m[5].y, m[6].y, m[7].y}; KGE_PUTB3(4 * pj + 1, pq, v) }
@@ -1027,9 +1027,11 @@ __global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
         bool cv[NT];
 #pragma unroll
         for (int j = 0; j < NT; j++) cv[j] = l16 + 16 * j < Dr;
+        // (the padding columns of the staged rows are exact zeros -- the matrix image's padding columns are -- so rows are read and
+        // written whole: a mask per element compiled into an exec-mask branch around every LDS access)
         auto ldrow = [&](const float *p, float (&x)[NT]) {
 #pragma unroll
-            for (int j = 0; j < NT; j++) x[j] = cv[j] ? p[l16 + 16 * j] : 0.f;
+            for (int j = 0; j < NT; j++) x[j] = p[l16 + 16 * j];
         };
         auto dotT = [&](const float (&x)[NT], const float (&y)[NT]) {
             float sdot = 0.f;
@@ -1115,7 +1117,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
                     normalize_bwdT(xn, sg, inv, uc);                                    // (an inactive hinge: zeros in, zeros out)
                     if (active) {
 #pragma unroll
-                        for (int j = 0; j < NT; j++) if (cv[j]) rowp[(2 + k) * LDC + l16 + 16 * j] = sg[j];
+                        for (int j = 0; j < NT; j++) rowp[(2 + k) * LDC + l16 + 16 * j] = sg[j];
                     }
                 }
                 const float fc = (float)cnt;
@@ -1128,8 +1130,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm3_kernel(GemmArgs a) {
                 normalize_bwdT(tn, gt, inv_t, uc_t);
                 if (active) {
 #pragma unroll
-                    for (int j = 0; j < NT; j++)
-                        if (cv[j]) { rowp[l16 + 16 * j] = gh[j]; rowp[LDC + l16 + 16 * j] = gt[j]; }
+                    for (int j = 0; j < NT; j++) { rowp[l16 + 16 * j] = gh[j]; rowp[LDC + l16 + 16 * j] = gt[j]; }
                 }
             }
             if (lane < 16 && a.row_ent) a.row_ent[row0 + base + lane] = s_ent[base + lane];
