@@ -148,6 +148,13 @@ const char *kge_version(void);
  *   "hub_copies":        1 (default) = on the fp32-atomic TransH/TransD path, relation-side gradient rows that would
  *                        take >= 128 adds per step are accumulated in up to 64 copies and folded (same-address
  *                        atomics serialise); 0 = straight into the accumulators
+ *   "transr_bf16x3":     1 (default) = TransR's row GEMMs and wgrad (dims <= 208, multiples of 4) form the fp32 products as six
+ *                        bf16 x bf16 term products of an exact three-term split on the bf16 matrix pipe (error vs fp64 equal to the
+ *                        fp32 MFMA's); 0 = the fp32 MFMA kernels
+ *   "transr_groups":     TransR, device-sampled batches, 2 + negatives <= 16: 1 (default) = steps with well-filled relation buckets
+ *                        sort GROUPS by relation and keep a group's rows inside one 16-row sub-tile; 2 = at any size; 0 = never
+ *   "transr_fuse_vec":   1 (default) = with that layout the vector stage runs inside the projection's epilogue; 0 = as its own launch
+ *   "transr_fused":      1 = the one-kernel relation tile (projection + vector stage + dgrad; measured slower, default 0)
  *   "transr_v1":         test hooks for the TransR MFMA tilings (default 0 = automatic): 1 = always the 32x32x2 tiles; 2 = 16x16x4
  *                        tiles with the all-output-tiles wgrad and its 512-row spans forced; 3 = 16x16x4 tiles with the 32x32x2 wgrad
  *   "time_emit":         N > 0 = bracket every N-th launch of the TransE emit kernel with HIP events on its launch stream
