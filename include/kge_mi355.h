@@ -154,7 +154,6 @@ const char *kge_version(void);
  *   "transr_groups":     TransR, device-sampled batches, 2 + negatives <= 16: 1 (default) = steps with well-filled relation buckets
  *                        sort GROUPS by relation and keep a group's rows inside one 16-row sub-tile; 2 = at any size; 0 = never
  *   "transr_fuse_vec":   1 (default) = with that layout the vector stage runs inside the projection's epilogue; 0 = as its own launch
- *   "transr_fused":      1 = the one-kernel relation tile (projection + vector stage + dgrad; measured slower, default 0)
  *   "transr_v1":         test hooks for the TransR MFMA tilings (default 0 = automatic): 1 = always the 32x32x2 tiles; 2 = 16x16x4
  *                        tiles with the all-output-tiles wgrad and its 512-row spans forced; 3 = 16x16x4 tiles with the 32x32x2 wgrad
  *   "time_emit":         N > 0 = bracket every N-th launch of the TransE emit kernel with HIP events on its launch stream

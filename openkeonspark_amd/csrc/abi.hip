@@ -226,7 +226,6 @@ int kge_set_option(const char *name, INT value) {
     if (n == "transr_bf16x3") { engine().transr_bf16x3 = value != 0; return KGE_OK; }
     if (n == "transr_groups") { engine().transr_groups = (int)value; return KGE_OK; }
     if (n == "transr_fuse_vec") { engine().transr_fuse_vec = value != 0; return KGE_OK; }
-    if (n == "transr_fused") { engine().transr_fused = value != 0; return KGE_OK; }
     if (n == "counts_fused") { engine().counts_fused = value != 0; return KGE_OK; }
     if (n == "counts_fused_diag") { engine().counts_fused_diag = (int)value; return KGE_OK; }
     if (n == "counts_fused_cap") { engine().counts_fused_cap = value > 0 ? (int)value : 0; return KGE_OK; }

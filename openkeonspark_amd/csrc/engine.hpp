@@ -77,7 +77,6 @@ struct Engine {
     int transr_bf16x3 = 1;      // TransR row GEMMs (projection, dgrad): fp32 products as six bf16 x bf16 term products of an exact three-term split, on the bf16 matrix pipe (transr.hip rows_gemm3_kernel); 0 = the fp32 MFMA kernels
     int transr_groups = 1;      // TransR, device-sampled batches, 2 + n <= 16: groups (not jobs) sorted by relation, a group's rows side by side in one 16-row sub-tile (transr.hip GemmArgs); 1 = steps with well-filled buckets, 2 = always, 0 = never
     int transr_fuse_vec = 1;    // group layout: the vector stage inside the projection's epilogue (0: transr_vec_kernel on P)
-    int transr_fused = 0;       // TransR, one sampled negative per positive: projection + vector stage + dgrad of a relation tile in one kernel (transr.hip fused_tile_kernel)
     int transr_lean = 1;        // TransR vector stage: the float4-per-lane kernel that also zero-fills GP (0 = generic fwdbwd_kernel + memset)
     int pair_counts = 1;        // TransH / TransD: int8 sign records keyed by (entity, relation) + per-pair backward (pairs.hip) instead of float records
     int pair_counts_min_neg = 0;   // ... from this many negatives per positive; 0 = the measured cross-over (TransH 5, TransD 3)

@@ -45,8 +45,6 @@ struct TrWork {
     int32_t *tile_rel = nullptr, *tile_row0 = nullptr, *n_tiles = nullptr;
     int32_t *bucket_rows = nullptr;   // group layout: start of every relation's ROW space ([R + 2]; bucket_start holds the group starts there)
     int64_t cap_rel_rows = 0, pad_ready = -1;
-    int32_t *bucket_start4 = nullptr, *tile_row0_4 = nullptr;   // fused tile path: the group-unit maps in ROW units (4 rows per group), for wgrad
-    int64_t cap_rel4 = 0, cap_tiles4 = 0;
     int32_t *rel_hist = nullptr;      // two alternating pairs of [kRelBins] bucket sizes + [kRelBins] scatter cursors
     int rel_parity = 0;
     void *sort_tmp = nullptr;
@@ -121,15 +119,6 @@ __global__ void prep_kernel(const int32_t *__restrict__ bh, const int32_t *__res
         keys[slot] = (int32_t)key;
         vals[slot] = (int32_t)slot;
         job_ent[slot] = (int32_t)e;
-    }
-}
-
-// fused tile path: one job per GROUP (key = the positive's relation), and the identity list wgrad walks the compact rows with
-__global__ void group_prep_kernel(const int32_t *__restrict__ br, long long n_pos, int32_t *__restrict__ keys, int32_t *__restrict__ vals,
-                                  int32_t *__restrict__ iota4) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < 4 * n_pos; i += (long long)gridDim.x * blockDim.x) {
-        if (i < n_pos) { keys[i] = br[i]; vals[i] = (int32_t)i; }
-        iota4[i] = (int32_t)i;
     }
 }
 
@@ -1568,328 +1557,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(GemmArgs a, float *__res
 #undef KGE_W3PUT
 }
 
-// ---------------------------------------------------------------------------------------------
-// Fused relation tile (one negative per positive, sampler-shaped, the positive's matrix for both: config #4's step):
-// projection -> vector stage -> dgrad of a tile of GROUPS in ONE kernel, the projected rows P and their gradients GP never
-// leaving the CU.  (TransR.py:16-17,52-75; before: project / vector stage / dgrad were three launches with P and GP written
-// to and read back from HBM between them, each launch with its own index chain.)
-//
-// Groups (not projection jobs) are ordered by relation.  A group owns FOUR consecutive rows of its tile: h, t, the one new entity x
-// of its negative, and a zero pad row -- exactly the four rows (v = 0..3) that ONE LANE holds of a 16x16x4 MFMA output tile
-// (acc[s2][t][v] = D[4 (lane >> 4) + v][16 t + (lane & 15)]).  So after the projection a lane has, for its group and its 13
-// columns, P_h, P_t and P_x side by side in registers, and the whole vector stage -- normalise, L1 scores, hinge, backward through
-// the normalisation -- is lane-local arithmetic plus reductions over the 16 lanes of a DPP row (team_sum<16>).  The pad row costs
-// a quarter of the matrix work and buys the absence of any data movement between the three stages.
-//   phase A  P = X M_r            rows gathered from ent_embeddings, M_r streamed in K chunks (as rows_gemm2_kernel)
-//   phase B  vector stage         in registers; GP overwrites P; the loss partial and g_rel (LDS, one atomic row per tile) on the way
-//   phase C  GP -> LDS in the A-operand layout (stays there for phase D) and, coalesced, -> the compact buffer wgrad reads
-//   phase D  G = GP M_r^T         A from LDS (resident), M_r^T streamed in K chunks; rows out as atomics or float records
-// RT 16-row sub-tiles per wave: 2 = 32 groups per workgroup (well-filled buckets), 1 = 16 groups (the reference's batch: a dozen
-// groups per relation; two workgroups per CU).
-// ---------------------------------------------------------------------------------------------
-constexpr int LDG = 218;          // GP in LDS, [row][col]: 218 = 26 mod 32 -> the A-operand reads (16 rows x 2 k) hit 32 distinct banks
-
-struct FusedArgs {
-    const float *ent, *mat, *rel;
-    float *g_ent, *g_rel;
-    const int32_t *bh, *bt, *br;
-    long long n_pos, stride;
-    const int32_t *sorted_groups, *bucket_start, *tile_rel, *tile_row0, *n_tiles;   // GROUP units, 32 groups per tile
-    int De, Dr, R;
-    float margin;
-    float *GPc;               // [4 n_pos, Dr] compact GP in sorted order (row 4 p + v of sorted group position p), read by wgrad
-    int32_t *job_ent;         // [4 n_pos] entity of each such row (pad rows: the head; their GP row is zero)
-    int32_t *bucket_start4, *tile_row0_4;   // the maps in row units, written here for wgrad
-    float *rec_out;           // dgrad rows as float records (large steps) instead of atomics; rec_dst = -1 for pad rows
-    int32_t *rec_dst;
-    FbArgs fb;                // loss hand-off (finish_loss)
-};
-
-template <int RT>
-__global__ __launch_bounds__(256, RT == 1 ? 2 : 1) void fused_tile_kernel(FusedArgs f) {
-    constexpr int NT = NT2;                 // 13 column tiles: widths up to 208
-    constexpr int ROWS = RM2 * RT;          // 64 or 128 rows
-    constexpr int GW = ROWS / 4;            // groups per workgroup
-    constexpr int KCD = RT == 1 ? 20 : 40;  // dgrad K chunk (columns of GP): the smaller one lets two workgroups share a CU's LDS
-    constexpr int LDBD = KCD + 2;
-    constexpr int LDBN = NT * 16;
-    // LDS: phase A staging (As, Bs) and phase C/D (GPs, Bd) share one buffer
-    constexpr int A_FLOATS = ROWS * LDA2 + KC2 * LDBN;
-    constexpr int D_FLOATS = ROWS * LDG + LDBN * LDBD;
-    constexpr int BUF = A_FLOATS > D_FLOATS ? A_FLOATS : D_FLOATS;
-    __shared__ __attribute__((aligned(16))) float buf[BUF];
-    __shared__ int s_ent[ROWS];
-    __shared__ int s_code[GW];
-    __shared__ float s_grel[LDBN];
-    __shared__ float red[4];
-    float *As = buf, *Bs = buf + ROWS * LDA2;
-    float *GPs = buf, *Bd = buf + ROWS * LDG;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = RT == 2 ? blockIdx.x : blockIdx.x >> 1;
-    const int half = RT == 2 ? 0 : (int)(blockIdx.x & 1);
-    float lsum = 0.f;
-    int g_count = 0, r = 0, gpos0 = 0;
-    if (tile < f.n_tiles[0]) {
-        r = f.tile_rel[tile];
-        gpos0 = f.tile_row0[tile] + half * GW;
-        g_count = max(0, min(GW, f.bucket_start[r + 1] - gpos0));
-        if (half == 0 && tid == 0) f.tile_row0_4[tile] = 4 * f.tile_row0[tile];
-    }
-    if (blockIdx.x == 0) for (int i = tid; i <= f.R + 1; i += 256) f.bucket_start4[i] = 4 * f.bucket_start[i];
-    if (g_count > 0) {     // (wave-uniform; every workgroup, also an empty one, meets in finish_loss below)
-        const int De = f.De, Dr = f.Dr;
-        if (tid < GW) {
-            const int g = min(tid, g_count - 1);                 // padding groups repeat the last live one (zeroed on the way into LDS)
-            const int b = f.sorted_groups[gpos0 + g];
-            const int h = f.bh[b], t = f.bt[b];
-            const int nh = f.bh[b + f.stride], nt = f.bt[b + f.stride];
-            const int code = nh != h ? 0 : 1;                     // 0: the negative has a new head, 1: a new tail (Base.cpp:118-130)
-            s_code[tid] = code;
-            s_ent[4 * tid] = h; s_ent[4 * tid + 1] = t; s_ent[4 * tid + 2] = code == 0 ? nh : nt; s_ent[4 * tid + 3] = h;
-        }
-        for (int i = tid; i < LDBN; i += 256) s_grel[i] = 0.f;
-        __syncthreads();
-        if (tid < 4 * g_count) {       // wgrad's view of these rows
-            f.job_ent[4 * gpos0 + tid] = s_ent[tid];
-            if (f.rec_dst) f.rec_dst[4 * gpos0 + tid] = (tid & 3) == 3 ? -1 : s_ent[tid];
-        }
-        const float *M = f.mat + (long long)r * De * Dr;
-        f32x4 acc[RT2][NT];
-#pragma unroll
-        for (int s2 = 0; s2 < RT2; s2++)
-#pragma unroll
-            for (int t = 0; t < NT; t++) acc[s2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int rows_live = 4 * g_count;
-        // ---------------- phase A: P = X . M_r ----------------
-        {
-            constexpr int AQ = KC2 / 4, NA = (ROWS * AQ + 255) / 256;
-            constexpr int BQ = LDBN / 4, NB = (KC2 * BQ + 255) / 256;
-            float4 ra[NA], rb[NB];
-            const int K = De;
-#define KGE_F_LOAD(k0_)                                                                                                  \
-    {                                                                                                                    \
-        static_for<0, NA>([&](auto uc) {                                                                                 \
-            constexpr int u = decltype(uc)::value;                                                                       \
-            const int idx = min(tid + 256 * u, ROWS * AQ - 1);                                                           \
-            const int i = idx / AQ, q = idx - i * AQ;                                                                    \
-            ra[u] = *reinterpret_cast<const float4 *>(f.ent + (long long)s_ent[min(i, rows_live - 1)] * De + min((k0_) + 4 * q, K - 4)); \
-        });                                                                                                              \
-        static_for<0, NB>([&](auto uc) {                                                                                 \
-            constexpr int u = decltype(uc)::value;                                                                       \
-            const int idx = min(tid + 256 * u, KC2 * BQ - 1);                                                            \
-            const int rr = idx / BQ, q = idx - rr * BQ;                                                                  \
-            rb[u] = *reinterpret_cast<const float4 *>(M + (long long)min((k0_) + rr, K - 1) * Dr + min(4 * q, Dr - 4));  \
-        });                                                                                                              \
-    }
-            KGE_F_LOAD(0)
-            for (int k0 = 0; k0 < K; k0 += KC2) {
-                if (k0 > 0) __syncthreads();
-                static_for<0, NA>([&](auto uc) {
-                    constexpr int u = decltype(uc)::value;
-                    const int idx = tid + 256 * u;
-                    if (idx < ROWS * AQ) {
-                        const int i = idx / AQ, q = idx - i * AQ;
-                        const float4 v = keep_if(i < rows_live && (i & 3) != 3 && k0 + 4 * q < K, ra[u]);      // pad rows and padding groups: zero
-                        float2 *dst = reinterpret_cast<float2 *>(&As[i * LDA2 + 4 * q]);
-                        dst[0] = make_float2(v.x, v.y);
-                        dst[1] = make_float2(v.z, v.w);
-                    }
-                });
-                static_for<0, NB>([&](auto uc) {
-                    constexpr int u = decltype(uc)::value;
-                    const int idx = tid + 256 * u;
-                    if (idx < KC2 * BQ) {
-                        const int rr = idx / BQ, q = idx - rr * BQ;
-                        *reinterpret_cast<float4 *>(&Bs[rr * LDBN + 4 * q]) = keep_if(k0 + rr < K && 4 * q < Dr, rb[u]);
-                    }
-                });
-                __syncthreads();
-                if (k0 + KC2 < K) KGE_F_LOAD(k0 + KC2)
-                if (wave * 16 < rows_live) gemm2_mfma_block<GEMM_PROJECT, NT, RT>(As, Bs, acc, wave, lane);
-            }
-#undef KGE_F_LOAD
-        }
-        // ---------------- phase B: the vector stage, in registers ----------------
-        const int col0 = lane & 15, q4 = lane >> 4;
-        float rr_[NT];
-        float inv_r; bool uc_r;
-        {
-            float ss = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; t++) { const int c = 16 * t + col0; rr_[t] = c < Dr ? f.rel[(long long)r * Dr + c] : 0.f; ss = __builtin_fmaf(rr_[t], rr_[t], ss); }
-            ss = team_sum<16>(ss);
-            uc_r = ss >= 1e-12f;
-            inv_r = 1.0f / sqrtf(uc_r ? ss : 1e-12f);
-#pragma unroll
-            for (int t = 0; t < NT; t++) rr_[t] *= inv_r;
-        }
-        const float unit = f.fb.unit;
-#pragma unroll
-        for (int s2 = 0; s2 < RT; s2++) {
-            const int gl = (4 * s2 + wave) * 4 + q4;          // this lane's group
-            const bool live = gl < g_count;
-            const int code = s_code[min(gl, GW - 1)];
-            float ssh = 0.f, sst = 0.f, ssx = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                ssh = __builtin_fmaf(acc[s2][t][0], acc[s2][t][0], ssh);
-                sst = __builtin_fmaf(acc[s2][t][1], acc[s2][t][1], sst);
-                ssx = __builtin_fmaf(acc[s2][t][2], acc[s2][t][2], ssx);
-            }
-            ssh = team_sum<16>(ssh); sst = team_sum<16>(sst); ssx = team_sum<16>(ssx);
-            const bool uch = ssh >= 1e-12f, uct = sst >= 1e-12f, ucx = ssx >= 1e-12f;
-            const float ih = 1.0f / sqrtf(uch ? ssh : 1e-12f), it = 1.0f / sqrtf(uct ? sst : 1e-12f), ix = 1.0f / sqrtf(ucx ? ssx : 1e-12f);
-            float sp = 0.f, sn = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const float hn = acc[s2][t][0] * ih, tn = acc[s2][t][1] * it, xn = acc[s2][t][2] * ix;
-                const float ep = hn + rr_[t] - tn;
-                const float en = code == 0 ? xn + rr_[t] - tn : hn + rr_[t] - xn;
-                sp += fabsf(ep); sn += fabsf(en);
-            }
-            sp = team_sum<16>(sp); sn = team_sum<16>(sn);
-            const float hv = sp - sn + f.margin;
-            const bool active = live && hv >= 0.f;             // tf.maximum routes a tie to the hinge
-            if (active && col0 == 0) lsum += hv;
-            const float w = active ? unit : 0.f;
-            // dL/d(normalised vectors) / w:  new head: h^: +sp, t^: -sp + sn, x^: -sn ;  new tail: h^: +sp - sn, t^: -sp, x^: +sn ;  r^: sp - sn
-            float dh = 0.f, dt = 0.f, dx = 0.f, dr = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const float hn = acc[s2][t][0] * ih, tn = acc[s2][t][1] * it, xn = acc[s2][t][2] * ix;
-                const float sgp = sgn(hn + rr_[t] - tn);
-                const float sgn_ = sgn(code == 0 ? xn + rr_[t] - tn : hn + rr_[t] - xn);
-                const float gh = code == 0 ? sgp : sgp - sgn_, gt = code == 0 ? sgn_ - sgp : -sgp, gx = code == 0 ? -sgn_ : sgn_;
-                dh = __builtin_fmaf(hn, gh, dh); dt = __builtin_fmaf(tn, gt, dt); dx = __builtin_fmaf(xn, gx, dx);
-                dr = __builtin_fmaf(rr_[t], sgp - sgn_, dr);
-            }
-            dh = team_sum<16>(dh); dt = team_sum<16>(dt); dx = team_sum<16>(dx); dr = team_sum<16>(dr);
-            if (!uch) dh = 0.f;
-            if (!uct) dt = 0.f;
-            if (!ucx) dx = 0.f;
-            if (!uc_r) dr = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const float hn = acc[s2][t][0] * ih, tn = acc[s2][t][1] * it, xn = acc[s2][t][2] * ix;
-                const float sgp = sgn(hn + rr_[t] - tn);
-                const float sgn_ = sgn(code == 0 ? xn + rr_[t] - tn : hn + rr_[t] - xn);
-                const float gh = code == 0 ? sgp : sgp - sgn_, gt = code == 0 ? sgn_ - sgp : -sgp, gx = code == 0 ? -sgn_ : sgn_;
-                acc[s2][t][0] = w * ih * (gh - dh * hn);
-                acc[s2][t][1] = w * it * (gt - dt * tn);
-                acc[s2][t][2] = w * ix * (gx - dx * xn);
-                acc[s2][t][3] = 0.f;
-                const float gr = w * inv_r * ((sgp - sgn_) - dr * rr_[t]);
-                if (gr != 0.f) atomicAdd(&s_grel[16 * t + col0], gr);
-            }
-        }
-        __syncthreads();      // phase A's LDS reads are done (GPs overlays As / Bs); s_grel complete
-        // ---------------- phase C: GP -> LDS (A-operand layout) and, from there, -> the compact buffer ----------------
-#pragma unroll
-        for (int s2 = 0; s2 < RT; s2++) {
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-#pragma unroll
-                for (int v = 0; v < 4; v++) GPs[((4 * s2 + wave) * 16 + 4 * q4 + v) * LDG + 16 * t + col0] = acc[s2][t][v];
-            }
-        }
-        if (tid < Dr && s_grel[tid] != 0.f)
-            __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(f.g_rel + (long long)r * Dr + tid), s_grel[tid]);
-        __syncthreads();
-        {
-            const int qd = Dr / 4;
-            for (int idx = tid; idx < rows_live * qd; idx += 256) {
-                const int i = idx / qd, q = idx - i * qd;
-                const float *src = GPs + i * LDG + 4 * q;
-                *reinterpret_cast<float4 *>(f.GPc + ((long long)(4 * gpos0 + i)) * Dr + 4 * q) = make_float4(src[0], src[1], src[2], src[3]);
-            }
-        }
-        // ---------------- phase D: G = GP . M_r^T ----------------
-#pragma unroll
-        for (int s2 = 0; s2 < RT2; s2++)
-#pragma unroll
-            for (int t = 0; t < NT; t++) acc[s2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        {
-            constexpr int BQ = KCD / 4, NB = (LDBN * BQ + 255) / 256;
-            constexpr int STEPS = KCD / 4;
-            float4 rb[NB];
-            const int K = Dr;
-#define KGE_D_LOAD(k0_)                                                                                                  \
-    static_for<0, NB>([&](auto uc) {                                                                                     \
-        constexpr int u = decltype(uc)::value;                                                                           \
-        const int idx = min(tid + 256 * u, LDBN * BQ - 1);                                                               \
-        const int jj = idx / BQ, q = idx - jj * BQ;                                                                      \
-        rb[u] = *reinterpret_cast<const float4 *>(M + (long long)min(jj, De - 1) * Dr + min((k0_) + 4 * q, K - 4));      \
-    });
-            KGE_D_LOAD(0)
-            for (int k0 = 0; k0 < K; k0 += KCD) {
-                if (k0 > 0) __syncthreads();
-                static_for<0, NB>([&](auto uc) {
-                    constexpr int u = decltype(uc)::value;
-                    const int idx = tid + 256 * u;
-                    if (idx < LDBN * BQ) {
-                        const int jj = idx / BQ, q = idx - jj * BQ;
-                        const float4 v = keep_if(jj < De && k0 + 4 * q < K, rb[u]);
-                        float2 *dst = reinterpret_cast<float2 *>(&Bd[jj * LDBD + 4 * q]);
-                        dst[0] = make_float2(v.x, v.y);
-                        dst[1] = make_float2(v.z, v.w);
-                    }
-                });
-                __syncthreads();
-                if (k0 + KCD < K) KGE_D_LOAD(k0 + KCD)
-                if (wave * 16 < rows_live) {
-                    const int kq = lane >> 4, j = lane & 15;
-                    const float *a_base[RT];
-#pragma unroll
-                    for (int s2 = 0; s2 < RT; s2++) a_base[s2] = GPs + ((4 * s2 + wave) * 16 + j) * LDG + k0 + kq;
-                    const float *b_base = Bd + j * LDBD + kq;
-                    float av[2][RT], bv[2][NT];
-                    auto fetch = [&](int bsel, int st) {
-#pragma unroll
-                        for (int s2 = 0; s2 < RT; s2++) av[bsel][s2] = (k0 + 4 * st + kq < LDBN) ? a_base[s2][4 * st] : 0.f;
-#pragma unroll
-                        for (int t = 0; t < NT; t++) bv[bsel][t] = b_base[t * 16 * LDBD + 4 * st];
-                    };
-                    fetch(0, 0);
-                    static_for<0, STEPS>([&](auto sc) {
-                        constexpr int st = decltype(sc)::value;
-                        constexpr int cur = st & 1;
-                        if constexpr (st + 1 < STEPS) fetch(cur ^ 1, st + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int t = 0; t < NT; t++)
-#pragma unroll
-                            for (int s2 = 0; s2 < RT; s2++) acc[s2][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][s2], bv[cur][t], acc[s2][t], 0, 0, 0);
-                    });
-                }
-            }
-#undef KGE_D_LOAD
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < RT; s2++) {
-            const int row_base = (4 * s2 + wave) * 16 + 4 * q4;
-            if (row_base >= rows_live) continue;
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const int c = 16 * t + col0;
-                if (c >= De) continue;
-#pragma unroll
-                for (int v = 0; v < 3; v++) {          // (v = 3: the pad row)
-                    const int row = row_base + v;
-                    if (f.rec_out) f.rec_out[(long long)(4 * gpos0 + row) * De + c] = acc[s2][t][v];
-                    else __builtin_amdgcn_global_atomic_fadd_f32(
-                            (__attribute__((address_space(1))) float *)(f.g_ent + (long long)s_ent[row] * De + c), acc[s2][t][v]);
-                }
-            }
-        }
-    }
-    {   // the wave's loss partial at its lane 0 (finish_loss reads lane 0 of each 64-lane team)
-        const float ws = team_sum<64>(lsum);
-        __syncthreads();
-        finish_loss<4>(f.fb, red, ws, lane, wave);
-    }
-}
-
 int bits_for(int64_t v) { int b = 1; while ((int64_t(1) << b) <= v) b++; return b; }
 
 }  // namespace
@@ -1909,65 +1576,6 @@ int launch_forward_backward_transr(const kge_model_desc &m, const float *const t
     if (blocks > 4096) blocks = 4096;
     // v2 kernels (16x16x4 MFMA, 128-row tiles): dims multiples of 4 up to 208, one workgroup covers all columns
     const bool v2 = De % 4 == 0 && Dr % 4 == 0 && De >= 4 && Dr >= 4 && De <= LDB2 && Dr <= LDB2 && engine().transr_v1 != 1;
-    // ---- fused relation tiles (fused_tile_kernel): one negative per positive drawn by the sampler, the positive's matrix for both,
-    // widths 196..208 (the full 13 x 13 tile grid of wgrad2_kernel), a grid the loss hand-off can count
-    {
-        const int64_t tiles32 = n_pos / 32 + R + 1;
-        const int rt = n_pos >= 64 * R ? 2 : 1;            // well-filled buckets: 32 groups per workgroup; else 16 (two per tile)
-        const int64_t grid = rt == 2 ? tiles32 : 2 * tiles32;
-        if (v2 && sampler_shaped && n_neg == 1 && m.negative_rel == 0 && De > 192 && Dr > 192 && engine().transr_fused && engine().transr_v1 == 0 &&
-            grid <= kMaxLossBlocks && (R + 1) * kRelSub <= kRelBins && !engine().counts_force_sort) {
-            if ((rc = ensure_loss_buffers())) return rc;
-            if (R + 2 > g_w.cap_rel4) { if ((rc = grow(g_w.bucket_start4, (size_t)R + 2, "transr bucket_start4"))) return rc; g_w.cap_rel4 = R + 2; }
-            if (tiles32 + 1 > g_w.cap_tiles4) { if ((rc = grow(g_w.tile_row0_4, (size_t)tiles32 + 1, "transr tile_row0_4"))) return rc; g_w.cap_tiles4 = tiles32 + 1; }
-            const int64_t rows4 = 4 * n_pos;
-            float *drec = nullptr;
-            int32_t *ddst = nullptr;
-            const bool records = engine().transr_dgrad_records && rows4 >= engine().transr_dgrad_records_min;
-            if (records && (rc = float_records_workspace(rows4, De, drec, ddst))) return rc;
-            hipLaunchKernelGGL(group_prep_kernel, dim3(blocks), dim3(256), 0, stream, d_r, (long long)n_pos, g_w.keys, g_w.vals, g_w.keys2);
-            if (!g_w.rel_hist) {
-                if ((rc = grow(g_w.rel_hist, 4 * (size_t)kRelBins, "transr relation histogram"))) return rc;
-                if ((rc = hip_check(hipMemset(g_w.rel_hist, 0, sizeof(int32_t) * 4 * kRelBins), "zero relation histogram"))) return rc;
-            }
-            int32_t *pair = g_w.rel_hist + (g_w.rel_parity ? 2 * kRelBins : 0), *other = g_w.rel_hist + (g_w.rel_parity ? 0 : 2 * kRelBins);
-            g_w.rel_parity ^= 1;
-            const unsigned tiles = (unsigned)((n_pos + kRelTile - 1) / kRelTile);
-            hipLaunchKernelGGL(rel_count_kernel, dim3(tiles), dim3(256), 0, stream, g_w.keys, (int)n_pos, ((int)R + 1) * kRelSub, pair, other);
-            SamplerArgs ride = {};
-            unsigned n_ride = 0;
-            if (upload_jump_table() == KGE_OK && !take_attached_sampler(ride, n_ride)) n_ride = 0;
-            hipLaunchKernelGGL(rel_scatter_kernel, dim3(tiles + n_ride), dim3(256), 0, stream, g_w.keys, g_w.vals, (int)n_pos, (int)R, pair,
-                               pair + kRelBins, g_w.vals2, g_w.bucket_start, g_w.tile_rel, g_w.tile_row0, g_w.n_tiles, 5, ride,
-                               (int)tiles, (int)n_ride, 0, (int32_t *)nullptr);
-            FusedArgs fa = {};
-            fa.ent = tables[0]; fa.mat = tables[2]; fa.rel = tables[1]; fa.g_ent = grads[0]; fa.g_rel = grads[1];
-            fa.bh = d_h; fa.bt = d_t; fa.br = d_r; fa.n_pos = n_pos; fa.stride = stride;
-            fa.sorted_groups = g_w.vals2; fa.bucket_start = g_w.bucket_start; fa.tile_rel = g_w.tile_rel; fa.tile_row0 = g_w.tile_row0;
-            fa.n_tiles = g_w.n_tiles; fa.De = De; fa.Dr = Dr; fa.R = (int)R; fa.margin = m.margin;
-            fa.GPc = g_w.GP; fa.job_ent = g_w.job_ent; fa.bucket_start4 = g_w.bucket_start4; fa.tile_row0_4 = g_w.tile_row0_4;
-            fa.rec_out = drec; fa.rec_dst = ddst;
-            guard_loss_stream(stream);
-            fa.fb.loss_partials = engine().dev.loss_partials; fa.fb.loss_out = d_loss; fa.fb.loss_ticket = engine().dev.loss_ticket;
-            fa.fb.unit = 1.0f / (float)denom;
-            if (rt == 2) hipLaunchKernelGGL(fused_tile_kernel<2>, dim3((unsigned)grid), dim3(256), 0, stream, fa);
-            else hipLaunchKernelGGL(fused_tile_kernel<1>, dim3((unsigned)grid), dim3(256), 0, stream, fa);
-            if (records) {
-                FloatRowSpace rs = {};
-                rs.g_ent = grads[0]; rs.E = m.ent_total; rs.R = 0; rs.hub_base = m.ent_total; rs.hub_rows = 1; rs.rows = m.ent_total;
-                if ((rc = float_records_reduce(rows4, De, rs, stream))) return rc;
-            }
-            GemmArgs gw = {};
-            gw.ent = tables[0]; gw.mat = tables[2]; gw.GP = g_w.GP; gw.P = nullptr; gw.g_ent = grads[0];
-            gw.sorted_slots = g_w.keys2; gw.job_ent = g_w.job_ent; gw.bucket_start = g_w.bucket_start4;
-            gw.tile_rel = g_w.tile_rel; gw.tile_row0 = g_w.tile_row0_4; gw.n_tiles = g_w.n_tiles;
-            gw.De = De; gw.Dr = Dr; gw.rec_out = nullptr; gw.rec_dst = nullptr;
-            const int span = rows4 >= 256 * R ? SPAN2 : 1;
-            const dim3 wg2((unsigned)((tiles32 + span - 1) / span), 2);
-            hipLaunchKernelGGL(wgrad2_kernel, wg2, dim3(256), 0, stream, gw, grads[2], span);
-            return hip_check(hipGetLastError(), "transr fused launch");
-        }
-    }
     // ---- group layout (GemmArgs): device-sampled batches with the positive's matrix for every negative, 2 + n <= 16 rows per group ----
     {
         const int U = 2 + (int)n_neg;

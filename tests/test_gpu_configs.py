@@ -208,19 +208,16 @@ def test_pair_count_path_many_negatives(wn_dir, fb_dir, model, graph, nbatches, 
 # ------------------------------------------------------------------------------------------------------------------
 # configs[3]: FB15k-237-shaped TransR 200 x 200, tilings chosen by the engine
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("path", ["fused relation tiles", "three kernels", "group layout", "group layout, separate vector stage"])
+@pytest.mark.parametrize("path", ["three kernels", "group layout", "group layout, separate vector stage"])
 @pytest.mark.parametrize("nbatches,B", [(0, 2721), (8, 34014)])
 def test_config4_fb15k237_transr(fb_dir, nbatches, B, path):
     """configs[3] at the reference's auto batch and at B = 34 014, device-sampled batches passed as such (what train_step does):
-    "fused relation tiles" = projection, vector stage and dgrad of a tile of groups in ONE kernel (csrc/transr.hip
-    fused_tile_kernel: 16 groups per workgroup at B = 2 721, 32 at B = 34 014 where dgrad's rows also go out as float records);
     "three kernels" = the separate project / vector stage / dgrad launches (jobs sorted by relation); "group layout" = groups
     sorted by relation, a group's rows side by side in one 16-row sub-tile, the vector stage inside the projection's epilogue
     (the default from ~64 rows per relation on; forced here at both sizes), or as its own launch.  All against the oracle
     (TransR.py:16-75)."""
     from openkeonspark_amd import _lib
     n, alpha = 1, 0.01
-    _lib.lib().kge_set_option(b"transr_fused", 1 if path.startswith("fused") else 0)
     _lib.lib().kge_set_option(b"transr_groups", 2 if path.startswith("group") else 0)
     _lib.lib().kge_set_option(b"transr_fuse_vec", 0 if path.endswith("separate vector stage") else 1)
     try:
@@ -233,7 +230,6 @@ def test_config4_fb15k237_transr(fb_dir, nbatches, B, path):
         run_steps(con, kg, orc, B, n, alpha, steps=2, name="config4 FB15k-237 TransR 200x200 B=%d (%s)" % (B, path), model="transr", dims=(200, 200),
                   sampler_shaped=True)
     finally:
-        _lib.lib().kge_set_option(b"transr_fused", 0)
         _lib.lib().kge_set_option(b"transr_groups", 1)
         _lib.lib().kge_set_option(b"transr_fuse_vec", 1)
 

@@ -280,10 +280,13 @@ def _driver_worker(rank, world, port, out_dir):
             "--train_times", "3", "--work_threads", "4"]
     con = dt.main_fun(dt.parse_args(args))
     np.savez(os.path.join(out_dir, "drv_w%d_r%d.npz" % (world, rank)), step=con.global_step, **con.get_parameters())
+    # (main_fun made and destroyed its own process group; the second call makes another one: on a port of its own -- a rendezvous
+    # on the port the first group's store is still closing was refused once in a soak run, "Connection reset by peer")
+    os.environ["MASTER_PORT"] = str(port + 500)
     met = dt.main_fun(dt.parse_args(args + ["--mode", "test"]))
     import json
     json.dump(met, open(os.path.join(out_dir, "drvlp_w%d_r%d.json" % (world, rank)), "w"))
-    if world > 1:
+    if world > 1 and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
